@@ -1,0 +1,154 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the real reference
+(tests/golden/make_goldens.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, unet_ref
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def split(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("name", ["unet_f8x16", "unet_f8x16x32x64", "unet_f16_c3"])
+def test_unet_forward_backward_matches_reference(name):
+    g = load(name)
+    st = {k: v.clone() for k, v in split(g, "init/").items()}
+    params = [k for k in st if not ("running_" in k or "num_batches" in k)]
+    for k in params:
+        st[k].requires_grad_(True)
+    nb = {}
+    logits = unet_ref.unet_forward(g["x"], st, train=True, new_buffers=nb)
+    loss = loss_ref.ce_dice(logits, g["y"], 1.0, 1.0, 255)
+    loss.backward()
+    assert relerr(logits.detach(), g["logits"]) < 1e-5
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert torch.equal(logits.argmax(1), g["argmax"])
+    for k in params:
+        ref = g["grad/" + k]
+        if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k:
+            # conv bias in front of train-mode BN: true gradient is ~0
+            assert (st[k].grad - ref).abs().max() < 1e-6
+        else:
+            assert relerr(st[k].grad, ref) < 1e-4, k
+    for k, v in split(g, "buf1/").items():
+        got = nb[k]
+        if v.dtype == torch.int64:
+            assert torch.equal(got, v)
+        else:
+            assert relerr(got, v) < 1e-5, k
+
+
+def test_repunet_groupnorm_matches_reference():
+    for name, ks in (("repunet_gn_f8x16_k35", [3, 5]), ("repunet_gn_f8_k3", [3])):
+        g = load(name)
+        st = {k: v.clone().requires_grad_(True) for k, v in split(g, "init/").items()}
+        logits = unet_ref.repunet_forward(g["x"], st, ks, norm="group")
+        loss = loss_ref.ce_dice(logits, g["y"], 1.0, 1.0, 255)
+        loss.backward()
+        assert relerr(logits.detach(), g["logits"]) < 1e-5
+        assert abs(float(loss) - float(g["loss"])) < 1e-6
+        for k in st:
+            assert relerr(st[k].grad, g["grad/" + k]) < 2e-4, k
+
+
+@pytest.mark.parametrize("name,ks", [("fold_k3", [3]), ("fold_k35", [3, 5])])
+def test_fold_bit_exact(name, ks):
+    g = load(name)
+    pre = {k: v.clone() for k, v in split(g, "pre/").items()}
+    post = split(g, "post/")
+    folded = unet_ref.fold_state(pre, ks)
+    assert set(folded) == set(post)
+    for k in post:
+        assert torch.equal(folded[k], post[k]), k          # bit-exact
+    with torch.no_grad():
+        y_multi = unet_ref.repunet_forward(g["x"], pre, ks, norm="batch", train=False)
+        y_dep = unet_ref.repunet_forward(g["x"], folded, ks, norm="batch", train=False)
+    assert relerr(y_multi, g["logits_multibranch"]) < 1e-5
+    assert relerr(y_dep, g["logits_deploy"]) < 1e-5
+    assert (y_multi - y_dep).abs().max() < 1e-4
+
+
+def test_loss_cases():
+    g = load("loss_cases")
+    for tag, cw, dw in (("A", 1, 1), ("B", 1, 1), ("C", 1, 1)):
+        lg = g[f"{tag}/logits"].clone().requires_grad_(True)
+        y = g[f"{tag}/target"]
+        loss = loss_ref.ce_dice(lg, y, cw, dw, 255)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"{tag}/loss"])) < 1e-6
+        assert abs(float(loss_ref.dice(lg.detach(), y)) - float(g[f"{tag}/dice"])) < 1e-6
+        assert abs(float(loss_ref.cross_entropy(lg.detach(), y, 255)) - float(g[f"{tag}/ce"])) < 1e-6
+        assert relerr(lg.grad, g[f"{tag}/dlogits"]) < 1e-5
+    lg = g["A/logits"].clone().requires_grad_(True)
+    loss = loss_ref.ce_dice(lg, g["A/target"], 0.3, 0.7, 255)
+    loss.backward()
+    assert abs(float(loss) - float(g["D/loss"])) < 1e-6
+    assert relerr(lg.grad, g["D/dlogits"]) < 1e-5
+    lg = g["A/logits"].clone().requires_grad_(True)
+    loss = loss_ref.cross_entropy(lg, g["E/target"], 255)
+    loss.backward()
+    assert abs(float(loss) - float(g["E/loss"])) < 1e-6
+    assert relerr(lg.grad, g["E/dlogits"]) < 1e-5
+    assert int(g["E/dice_raises"]) == 1
+    with pytest.raises(RuntimeError):
+        loss_ref.dice(g["A/logits"], g["E/target"])
+
+
+def test_ensemble_per_pixel():
+    g = load("ensemble")
+    pred = loss_ref.ensemble_fuse(g["logits1"], g["logits2"], float(g["entropy_thresh"]))
+    assert torch.equal(pred, g["pred_ens"])
+    assert torch.equal(g["logits1"].argmax(1), g["pred1"])
+    assert torch.equal(g["logits2"].argmax(1), g["pred2"])
+    # the fixture exercises all three branches
+    assert (g["pred_ens"] != g["pred1"]).any() and (g["pred_ens"] != g["pred2"]).any()
+
+
+def test_metrics():
+    j = json.load(open(os.path.join(G, "metrics.json")))
+    got = loss_ref.seg_metrics(torch.tensor(j["pred"]), torch.tensor(j["target"]), 2)
+    for k, v in j["metrics"].items():
+        assert abs(got[k] - v) < 1e-7, k
+    z = torch.zeros(1, 6, 6, dtype=torch.long)
+    got0 = loss_ref.seg_metrics(z, z, 2)
+    for k, v in j["empty_metrics"].items():
+        assert abs(got0[k] - v) < 1e-7, k
+
+
+@pytest.mark.parametrize("name", ["unet_f8x16", "unet_f8x16x32x64"])
+def test_step_matches_reference_step_batch(name):
+    """oracle fwd/bwd + oracle clip+AdamW == reference step_batch parameters after one step."""
+    g = load(name)
+    st = {k: v.clone() for k, v in split(g, "init/").items()}
+    names = [k for k in st if not ("running_" in k or "num_batches" in k)]
+    for k in names:
+        st[k].requires_grad_(True)
+    loss = loss_ref.ce_dice(unet_ref.unet_forward(g["x"], st, True, {}), g["y"], 1.0, 1.0, 255)
+    loss.backward()
+    assert abs(float(loss) - float(g["step/main_loss"])) < 1e-6
+    ps = [st[k].detach().clone() for k in names]
+    gs = [st[k].grad for k in names]
+    m = [torch.zeros_like(p) for p in ps]
+    v = [torch.zeros_like(p) for p in ps]
+    loss_ref.clip_adamw_step(ps, gs, m, v, 1, 1e-4, 1e-4, 1.0)
+    for k, p in zip(names, ps):
+        # conv biases in front of train-mode BN have noise-only gradients (~1e-8), so their first
+        # Adam update lr*g/(|g|+eps) is noise of size <= lr: bound them by one full step instead
+        noise = ".double_conv.0.bias" in k or ".double_conv.3.bias" in k
+        assert (p - g["step/" + k]).abs().max() < (2.1e-4 if noise else 5e-6), k
