@@ -1,0 +1,134 @@
+/* libunet_hip.so -- C ABI of the MI355X (gfx950) U-Net hot path.
+ *
+ * The reference (abin102/unet) has no native/FFI boundary: its hot path is reached through
+ * torch.nn modules (models/unet.py, models/reparm_unet.py, losses/segmentation.py).  Each entry
+ * point below names the reference call site whose ATen/cuDNN work it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees or
+ *     retains device memory (workspaces are arguments);
+ *   - `stream` is a hipStream_t; every call only enqueues work on it;
+ *   - dtype: UNET_F32 (0) or UNET_BF16 (1) = storage type of activations and packed weights;
+ *     accumulation is always fp32 (fp64 for cross-workgroup sums);
+ *   - activations are NHWC; a tensor argument is (pointer, ld = elements per pixel, off = first
+ *     channel) so kernels read and write channel slices of wider buffers (the skip-concat buffer);
+ *   - return 0 on success, negative on error with text from unet_last_error() (thread local).
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_F32 0
+#define UNET_BF16 1
+
+int unet_version(void);
+const char* unet_last_error(void);
+
+/* ---- MFMA implicit-GEMM convolution ---------------------------------------------------------
+ * nn.Conv2d(k=3,pad=1) forward and dgrad (models/unet.py:10,13), the RepUNet kx1/1xk/kxk
+ * branches and deployed conv (models/reparm_unet.py:55-61,139), nn.ConvTranspose2d(2,2) forward
+ * (epi=1: 1x1 GEMM + 2x2 pixel shuffle straight into the concat buffer, models/unet.py:35,53,59)
+ * and its dgrad (kh=2,kw=1,stride_h=2 on the [N,2H,W,2C] view of the output gradient).
+ * w: packed [kh*kw][Cout][Cin] (unet_pack_weights).  bias/stats may be NULL.  stats receives
+ * unet_conv_tiles() rows of [Cout][2] = per-tile (sum, sum of squares) of the fp32 outputs. */
+int unet_conv_tiles(int N, int Hout, int Wout);
+int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
+                  const void* x, const void* w, const float* bias, void* y, float* stats,
+                  int N, int Hin, int Win, int Cin, int ldx, int xoff,
+                  int Hout, int Wout, int Cout, int ldy, int yoff,
+                  int pad_h, int pad_w,
+                  void* y2, int ldy2, int yoff2, int csplit, void* stream);
+/* csplit > 0: output channels >= csplit are written to y2 (channel co - csplit) instead of y; the
+ * dgrad of the first decoder conv uses it to hand the skip half and the upsampled half of the
+ * concat gradient to two dense buffers (torch.cat backward, models/unet.py:59). */
+
+/* weight gradient of the same convolutions (autograd of models/unet.py:10,13,35).
+ * slab: workspace of unet_conv_wgrad_splits() * kh*kw*Cout*Cin floats.
+ * dw[o][i][tap] for tap in [dw_tap0, dw_tap0+kh*kw) of dw_taps taps per (o,i). */
+int unet_conv_wgrad_splits(int dtype, int N, int Hout, int Wout, int Cin, int Cout);
+int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
+                    const void* dz, const void* x, float* slab, float* dw, int accumulate,
+                    int dw_taps, int dw_tap0,
+                    int N, int Hin, int Win, int Cin, int ldx, int xoff,
+                    int Hout, int Wout, int Cout, int lddz, int dzoff,
+                    int pad_h, int pad_w, void* stream);
+/* ConvTranspose2d weight grad: call unet_conv_wgrad(kh=2,kw=1,stride_h=2, dw=NULL) with dz := the
+ * layer input [N,H,W,Ci] and x := the [N,2H,W,2*Co] view of the output gradient (the slab sum is
+ * then skipped), then this on the slab [nsplit][2][Ci][2*Co] -> dw (Ci,Co,2,2). */
+int unet_convT_wgrad_reduce(const float* slab, float* dw, int nsplit, int Ci, int Co, void* stream);
+
+/* ---- first conv (Cin<=4, fp32 image in) and final 1x1 conv (fp32 NCHW logits out) -----------
+ * models/unet.py:30 (in_channels=1) and models/unet.py:39,62. */
+int unet_conv_first_rows(int dtype, int N, int H, int W, int Cout);
+int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, const float* w, const float* bias, void* z, float* stats,
+                        int N, int H, int W, int Cin, int Cout, void* stream);
+int unet_conv_first_wgrad(int dtype, int kh, int kw, const void* dz, const float* x, float* dw,
+                          int N, int H, int W, int Cin, int Cout, double* acc_ws, void* stream);
+int unet_conv_out_fwd(int dtype, const void* x, int ldx, int xoff, const float* w, const float* bias, float* logits,
+                      long long M, long long HW, int C, int K, void* stream);
+int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, int xoff, const float* w,
+                      void* dx, float* dw, float* db, long long M, long long HW, int C, int K,
+                      double* acc_ws, void* stream);
+
+/* fp32 master weights -> packed compute-dtype images.  mode 0 conv fwd, 1 conv dgrad (flipped,
+ * transposed), 2 convT fwd, 3 convT dgrad.  O,I = dims 0,1 of the source tensor. */
+int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, int I, int ntaps, void* stream);
+int unet_cast(int dtype, int to_f32, const void* src, void* dst, long long n, void* stream);
+
+/* ---- BatchNorm2d (+ReLU) -- models/unet.py:11-12,14-15 --------------------------------------
+ * train: batch mean / biased variance normalise, running stats use unbiased variance, momentum 0.1 */
+int unet_bn_finalize(const float* stat_rows, int nrows, int C, long long count,
+                     const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, long long* num_batches_tracked,
+                     float momentum, float eps,
+                     float* scale, float* shift, float* mean, float* invstd,
+                     double* acc_ws, void* stream);
+int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                        const float* running_var, float eps, float* scale, float* shift, void* stream);
+/* y = act(z*scale + shift) */
+int unet_affine_act(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
+                    const float* scale, const float* shift, long long M, int C, void* stream);
+/* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z */
+int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                     void* dz, int ldo, int ooff,
+                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                     float* dgamma, float* dbeta, float* dbias,
+                     float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
+int unet_relu_bwd(int dtype, const void* dy, int ldd, int doff, const void* y, int ldy, int yoff,
+                  void* dz, int ldo, int ooff, long long M, int C, void* stream);
+int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, long long M, int C, float* out, int accumulate,
+                     double* acc_ws, void* stream);
+
+/* ---- MaxPool2d(2,2) with argmax -- models/unet.py:26,47 --------------------------------------
+ * code[n,ho,wo,c] = 2*dh+dw of the winner (ATen tie rule: first in row-major order, NaN wins);
+ * int64 index of torch = (2*ho+dh)*W + 2*wo+dw.  bwd adds the skip-connection gradient. */
+int unet_maxpool2x2_fwd(int dtype, const void* x, int ldx, int xoff, void* y, uint8_t* code,
+                        int N, int H, int W, int C, void* stream);
+int unet_maxpool2x2_bwd(int dtype, const void* dy, const uint8_t* code, const void* dskip, int lds, int soff,
+                        void* dx, int N, int H, int W, int C, void* stream);
+
+/* ---- Dice + CE -- losses/segmentation.py:5-27 ------------------------------------------------
+ * logits NCHW fp32, target int64.  acc_ws: N*C*3+3 doubles, shared by fwd and bwd.
+ * out4 = {loss, ce, dice, count of labels the reference would have raised on}. */
+int unet_dice_ce_fwd(const float* logits, const long long* target, int N, int C, long long HW,
+                     float ce_weight, float dice_weight, long long ignore_index, int ce_only, double eps,
+                     double* acc_ws, float* out4, void* stream);
+int unet_dice_ce_bwd(const float* logits, const long long* target, int N, int C, long long HW,
+                     float ce_weight, float dice_weight, long long ignore_index, int ce_only, double eps,
+                     const double* acc_ws, const float* grad_out, float* dlogits, void* stream);
+/* logits.argmax(1) -- trainer.py:119, utils/eval_utils.py:103 */
+int unet_argmax(const float* logits, long long* out, int N, int C, long long HW, void* stream);
+/* entropy-weighted two-model fusion per pixel -- eval_ensemble.py:9-11,77-99 */
+int unet_ensemble_fuse(const float* logits1, const float* logits2, long long* out, int N, int C, long long HW,
+                       float entropy_thresh, void* stream);
+/* confusion counts for calculate_segmentation_metrics -- utils/eval_utils.py:16-40; counts[66] */
+int unet_seg_counts(const long long* pred, const long long* target, long long total, int K,
+                    unsigned long long* counts, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

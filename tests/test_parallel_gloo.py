@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel host logic: arrival-order bucketing, averaging,
+rank-0 broadcast, and batch sharding that matches the reference's DistributedSampler use."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from unet_amd.parallel import BucketReducer, DataParallel
+        # --- bucketed averaging in arrival order
+        red = BucketReducer(bucket_bytes=200)
+        g = torch.Generator().manual_seed(100 + rank)
+        names = [f"p{i}" for i in range(7)]
+        shapes = [(3, 5), (40,), (2, 2, 2), (64,), (1,), (30, 2), (7,)]
+        ts = [torch.randn(*s, generator=g) for s in shapes]
+        for i in range(0, 7, 2):
+            red.add(names[i:i + 2], ts[i:i + 2])
+        avg = red.finish()
+        want = []
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            want.append([torch.randn(*s, generator=gr) for s in shapes])
+        ok = red.buckets_launched >= 3
+        for i, n in enumerate(names):
+            ref = sum(w[i] for w in want) / world
+            ok = ok and torch.allclose(avg[n], ref, atol=1e-6) and avg[n].shape == ref.shape
+        # --- wrapper: rank-0 broadcast of parameters and buffers, gradient averaging into p.grad
+        torch.manual_seed(rank)              # different init per rank on purpose
+        net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.BatchNorm1d(3))
+        dp = DataParallel(net, bucket_cap_mb=1e-5)
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [b.reshape(-1).float() for b in net.buffers()])
+        gathered = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(gathered, flat)
+        ok = ok and all(torch.equal(gathered[0], x) for x in gathered)
+        x = torch.randn(6, 4, generator=torch.Generator().manual_seed(7 + rank))
+        dp(x).square().mean().backward()
+        local = {n: p.grad.clone() for n, p in net.named_parameters()}
+        for n in reversed(list(local)):       # the engine would call the hook in backward order
+            net._grad_hook([n], [local[n]])
+        dp.finish_grad_sync()
+        for n, p in net.named_parameters():
+            parts = [torch.zeros_like(local[n]) for _ in range(world)]
+            dist.all_gather(parts, local[n])
+            ok = ok and torch.allclose(p.grad, sum(parts) / world, atol=1e-6)
+        # --- sharding: rank r takes samples r::W of the epoch permutation, like DistributedSampler
+        from torch.utils.data import DistributedSampler
+        ds = list(range(10))
+        s = DistributedSampler(ds, num_replicas=world, rank=rank, shuffle=True, seed=42)
+        s.set_epoch(3)
+        mine = torch.tensor(list(s))
+        allidx = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allidx, mine)
+        ok = ok and sorted(torch.cat(allidx).tolist()) == sorted(ds)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

@@ -1,0 +1,464 @@
+// The two convolutions of the U-Net that do not map to MFMA tiles (gfx950), plus weight packing.
+//
+//   first conv  : Conv2d(Cin<=4 -> Cout, kxk)   (reference models/unet.py:30 with in_channels=1)
+//                 bandwidth-bound on its OUTPUT (reads 4 B/pixel, writes Cout*sizeof(T))
+//   final conv  : Conv2d(C -> n_classes<=8, 1x1) (reference models/unet.py:39,62), raw NCHW fp32 logits
+//                 bandwidth-bound on its INPUT
+//   pack        : fp32 OIHW / (Cin,Cout,2,2) master weights -> [tap][Cout][Cin] compute-dtype images
+#include "common.h"
+
+#define MAX_GRID 2048
+
+// ------------------------------------------------------------------------------------------------
+// first conv forward: x fp32 [N,H,W,Cin], w fp32 OIHW, z T [N,H,W,Cout] + BN partial rows [grid][Cout][2]
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ z,
+                                                             float* __restrict__ stats, int N, int H, int W, int Cin, int Cout) {
+    constexpr int EPV = TT<T>::EPV, NT = KH * KW, PH = KH / 2, PW = KW / 2;
+    extern __shared__ float sm[];                       // weights [tap][ci][Cout] then reduction scratch
+    const int G = Cout / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    for (int i = threadIdx.x; i < NT * Cin * Cout; i += 256) {
+        const int co = i % Cout, r = i / Cout, ci = r % Cin, tap = r / Cin;
+        sm[i] = w[((size_t)co * Cin + ci) * NT + tap];
+    }
+    __syncthreads();
+    float s1[EPV], s2[EPV], b[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s1[e] = s2[e] = 0.f; b[e] = (bias != nullptr && active) ? bias[cg * EPV + e] : 0.f; }
+    const long long M = (long long)N * H * W;
+    if (active) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < M; p += (long long)gridDim.x * PL) {
+            const int wq = (int)(p % W);
+            const long long r = p / W;
+            const int hq = (int)(r % H);
+            const long long nb = (r / H) * H;             // n*H
+            float acc[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) acc[e] = b[e];
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const int hh = hq + kh - PH;
+                if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int ww = wq + kw - PW;
+                    if (ww < 0 || ww >= W) continue;
+                    const float* xp = x + ((nb + hh) * W + ww) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const float xv = xp[ci];
+                        const float* wv = sm + ((kh * KW + kw) * Cin + ci) * Cout + cg * EPV;
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) acc[e] = fmaf(xv, wv[e], acc[e]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { s1[e] += acc[e]; s2[e] += acc[e] * acc[e]; }
+            *(uint4*)(z + p * Cout + cg * EPV) = Vec16<T>::pack(acc);
+        }
+    }
+    if (stats != nullptr) {
+        __syncthreads();
+        float* red = sm;                                 // [pl][Cout][2], reuses the weight area (>= 256*EPV*2 floats allotted)
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                red[(pl * Cout + cg * EPV + e) * 2 + 0] = s1[e];
+                red[(pl * Cout + cg * EPV + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Cout * 2; i += 256) {
+            float s = 0.f;
+            for (int p = 0; p < PL; ++p) s += red[p * Cout * 2 + i];
+            stats[(size_t)blockIdx.x * Cout * 2 + i] = s;
+        }
+    }
+}
+
+// first conv weight grad: dW[co][ci][tap] = sum_p dz[p][co] * x[p+tap][ci]; one launch handles input
+// channel `ci`; fp64 atomics into acc[Cout][NT] then converted by the caller.
+template <typename T, int KH, int KW>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T* __restrict__ dz, const float* __restrict__ x,
+                                                               int N, int H, int W, int Cin, int ci, int Cout,
+                                                               double* __restrict__ acc) {
+    constexpr int EPV = TT<T>::EPV, NT = KH * KW, PH = KH / 2, PW = KW / 2;
+    extern __shared__ float sm[];
+    const int G = Cout / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    float part[NT][EPV];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) part[t][e] = 0.f;
+    const long long M = (long long)N * H * W;
+    if (active) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < M; p += (long long)gridDim.x * PL) {
+            const int wq = (int)(p % W);
+            const long long r = p / W;
+            const int hq = (int)(r % H);
+            const long long nb = (r / H) * H;
+            float g[EPV];
+            Vec16<T>::unpack(*(const uint4*)(dz + p * Cout + cg * EPV), g);
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const int hh = hq + kh - PH;
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int ww = wq + kw - PW;
+                    const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                    const float xv = ok ? x[((nb + hh) * W + ww) * Cin + ci] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) part[kh * KW + kw][e] = fmaf(g[e], xv, part[kh * KW + kw][e]);
+                }
+            }
+        }
+    }
+    // reduce over pixel lanes one tap at a time: LDS [pl][cg][EPV]
+    const int per = G * EPV;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) sm[(pl * G + cg) * EPV + e] = part[t][e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += 256) {
+            float s = 0.f;
+            for (int p = 0; p < PL; ++p) s += sm[p * per + i];
+            atomicAdd(&acc[(size_t)i * NT + t], (double)s);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void first_wgrad_store_kernel(const double* __restrict__ acc, float* __restrict__ dw, int Cout, int Cin, int ci, int NT) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * NT) return;
+    const int co = i / NT, t = i - co * NT;
+    dw[((size_t)co * Cin + ci) * NT + t] = (float)acc[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// final 1x1 conv forward: x T [M][ld] -> logits fp32 NCHW [N][K][HW]; LP lanes cooperate on one pixel
+template <typename T, int K>
+__global__ __launch_bounds__(256) void conv_out_fwd_kernel(const T* __restrict__ x, int ldx, int xoff,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ logits, long long M, long long HW, int C, int LP) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV;
+    const int sub = threadIdx.x & (LP - 1);               // lane inside the pixel group
+    const int ppb = 256 / LP;                             // pixels per block pass
+    const int pslot = threadIdx.x / LP;
+    float wr[K][EPV];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) wr[k][e] = (sub < G) ? w[k * C + sub * EPV + e] : 0.f;
+    float bk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bk[k] = bias != nullptr ? bias[k] : 0.f;
+    // every lane of a wave runs the same trip count so the shuffles below see all lanes
+    const long long iters = (M + (long long)gridDim.x * ppb - 1) / ((long long)gridDim.x * ppb);
+    for (long long it = 0; it < iters; ++it) {
+        const long long p = (it * gridDim.x + blockIdx.x) * ppb + pslot;
+        float f[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) f[e] = 0.f;
+        if (p < M && sub < G) Vec16<T>::unpack(*(const uint4*)(x + p * ldx + xoff + sub * EPV), f);
+        float d[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s = fmaf(f[e], wr[k][e], s);
+            for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o);
+            d[k] = s + bk[k];
+        }
+        if (p < M && sub == 0) {
+            const long long n = p / HW, hw = p - n * HW;
+#pragma unroll
+            for (int k = 0; k < K; ++k) logits[(n * K + k) * HW + hw] = d[k];
+        }
+    }
+}
+
+// final conv backward: dl fp32 NCHW -> dx T [M][C] (dense), dW[K][C], db[K] via fp64 acc [K*C + K]
+template <typename T, int K>
+__global__ __launch_bounds__(256) void conv_out_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ x, int ldx, int xoff,
+                                                           const float* __restrict__ w, T* __restrict__ dx,
+                                                           long long M, long long HW, int C, double* __restrict__ acc) {
+    constexpr int EPV = TT<T>::EPV;
+    extern __shared__ float sm[];
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    float wr[K][EPV], pw[K][EPV], pb[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        pb[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { wr[k][e] = active ? w[k * C + cg * EPV + e] : 0.f; pw[k][e] = 0.f; }
+    }
+    if (active) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < M; p += (long long)gridDim.x * PL) {
+            const long long n = p / HW, hw = p - n * HW;
+            float f[EPV], o[EPV], g[K];
+            Vec16<T>::unpack(*(const uint4*)(x + p * ldx + xoff + cg * EPV), f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                g[k] = dl[(n * K + k) * HW + hw];
+                pb[k] += g[k];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) { o[e] = fmaf(g[k], wr[k][e], o[e]); pw[k][e] = fmaf(g[k], f[e], pw[k][e]); }
+            }
+            *(uint4*)(dx + p * C + cg * EPV) = Vec16<T>::pack(o);
+        }
+    }
+    // reduce dW partials over pixel lanes: LDS [pl][cg][K*EPV]
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) sm[(pl * G + cg) * K * EPV + k * EPV + e] = pw[k][e];
+    }
+    __syncthreads();
+    const int per = G * K * EPV;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < PL; ++p) s += sm[p * per + i];
+        const int cgi = i / (K * EPV), r = i - cgi * K * EPV, k = r / EPV, e = r - k * EPV;
+        atomicAdd(&acc[(size_t)k * C + cgi * EPV + e], (double)s);
+    }
+    __syncthreads();
+    // db: only the cg == 0 thread of each pixel lane carries a distinct copy
+    if (active && cg == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sm[pl * K + k] = pb[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float s = 0.f;
+        for (int p = 0; p < PL; ++p) s += sm[p * K + threadIdx.x];
+        atomicAdd(&acc[(size_t)K * C + threadIdx.x], (double)s);
+    }
+}
+
+__global__ void acc_store_kernel(const double* __restrict__ acc, float* __restrict__ a, int na, float* __restrict__ b, int nb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) a[i] = (float)acc[i];
+    else if (i < na + nb && b != nullptr) b[i - na] = (float)acc[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (one thread per destination element)
+//   mode 0 conv fwd   : dst[(tap*O + o)*I + i]          = src[(o*I + i)*T + tap]
+//   mode 1 conv dgrad : dst[((T-1-tap)*I + i)*O + o]     = src[(o*I + i)*T + tap]
+//   mode 2 convT fwd  : src (Ci,Co,2,2): dst[(q*Co + c)*Ci + ci]            = src[(ci*Co + c)*4 + q]
+//   mode 3 convT dgrad: dst[(i2*Ci + ci)*(2*Co) + j2*Co + c]                 = src[(ci*Co + c)*4 + i2*2 + j2]
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict__ dst, int mode, int O, int I, int NT) {
+    const size_t total = (size_t)O * I * NT;
+    for (size_t d = (size_t)blockIdx.x * blockDim.x + threadIdx.x; d < total; d += (size_t)gridDim.x * blockDim.x) {
+        size_t s;
+        if (mode == 0) {
+            const int i = (int)(d % I); const size_t r = d / I; const int o = (int)(r % O); const int tap = (int)(r / O);
+            s = ((size_t)o * I + i) * NT + tap;
+        } else if (mode == 1) {
+            const int o = (int)(d % O); const size_t r = d / O; const int i = (int)(r % I); const int tf = (int)(r / I);
+            s = ((size_t)o * I + i) * NT + (NT - 1 - tf);
+        } else if (mode == 2) {
+            // O = Ci (convT in), I = Co (convT out), NT = 4
+            const int ci = (int)(d % O); const size_t r = d / O; const int c = (int)(r % I); const int q = (int)(r / I);
+            s = ((size_t)ci * I + c) * 4 + q;
+        } else {
+            const int Co = I, Ci = O;
+            const int cc = (int)(d % (2 * Co)); const size_t r = d / (2 * Co); const int ci = (int)(r % Ci); const int i2 = (int)(r / Ci);
+            const int j2 = cc / Co, c = cc - j2 * Co;
+            s = ((size_t)ci * Co + c) * 4 + i2 * 2 + j2;
+        }
+        dst[d] = from_f32<T>(src[s]);
+    }
+}
+
+// convT weight-grad slab [nsplit][tap=i2][Ci][2*Co] -> dW (Ci,Co,2,2)
+__global__ void convT_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int Ci, int Co) {
+    const size_t total = (size_t)2 * Ci * 2 * Co;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + e];
+        const int cc = (int)(e % (2 * Co)); const size_t r = e / (2 * Co); const int ci = (int)(r % Ci); const int i2 = (int)(r / Ci);
+        const int j2 = cc / Co, c = cc - j2 * Co;
+        out[((size_t)ci * Co + c) * 4 + i2 * 2 + j2] = s;
+    }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = to_f32(src[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(long long M, int PL) {
+    long long g = (M + PL - 1) / PL;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int unet_conv_first_rows(int dtype, int N, int H, int W, int Cout) {
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    if (Cout <= 0 || Cout % epv) return -1;
+    const int G = Cout / epv;
+    if (G > 256) return -1;
+    return grid_for((long long)N * H * W, 256 / G);
+}
+
+extern "C" int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, const float* w, const float* bias, void* z, float* stats,
+                                   int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    UNET_CHECK(Cin >= 1 && Cin <= 4, "first-conv kernel serves Cin <= 4 (got %d)", Cin);
+    UNET_CHECK(Cout % 8 == 0 && Cout > 0, "Cout must be a multiple of 8");
+    const int rows = unet_conv_first_rows(dtype, N, H, W, Cout);
+    UNET_CHECK(rows > 0, "Cout=%d too wide for the first-conv kernel", Cout);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    size_t lds = (size_t)kh * kw * Cin * Cout * sizeof(float);
+    const size_t red = (size_t)256 * epv * 2 * sizeof(float);
+    if (lds < red) lds = red;
+    UNET_CHECK(lds <= 65536, "first-conv weights do not fit LDS");
+    hipStream_t s = (hipStream_t)stream;
+#define LF(T, A, B) hipLaunchKernelGGL((conv_first_fwd_kernel<T, A, B>), dim3(rows), dim3(256), lds, s, x, w, bias, (T*)z, stats, N, H, W, Cin, Cout)
+#define LFD(A, B) do { if (dtype == UNET_BF16) LF(__bf16, A, B); else LF(float, A, B); } while (0)
+    if (kh == 3 && kw == 3) LFD(3, 3);
+    else if (kh == 5 && kw == 5) LFD(5, 5);
+    else if (kh == 3 && kw == 1) LFD(3, 1);
+    else if (kh == 1 && kw == 3) LFD(1, 3);
+    else if (kh == 5 && kw == 1) LFD(5, 1);
+    else if (kh == 1 && kw == 5) LFD(1, 5);
+    else { unet_set_error("first conv: unsupported kernel %dx%d", kh, kw); return -1; }
+#undef LF
+#undef LFD
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_conv_first_wgrad(int dtype, int kh, int kw, const void* dz, const float* x, float* dw,
+                                     int N, int H, int W, int Cin, int Cout, double* acc_ws /* Cout*kh*kw doubles */, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    UNET_CHECK(Cin >= 1 && Cin <= 4 && Cout % 8 == 0, "first-conv wgrad: Cin<=4, Cout%%8==0");
+    const int rows = unet_conv_first_rows(dtype, N, H, W, Cout);
+    UNET_CHECK(rows > 0, "Cout=%d too wide", Cout);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    const int NT = kh * kw;
+    const size_t lds = (size_t)256 * epv * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = rows < 1024 ? rows : 1024;
+    for (int ci = 0; ci < Cin; ++ci) {
+        if (hipMemsetAsync(acc_ws, 0, sizeof(double) * Cout * NT, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+#define LW(T, A, B) hipLaunchKernelGGL((conv_first_wgrad_kernel<T, A, B>), dim3(grid), dim3(256), lds, s, (const T*)dz, x, N, H, W, Cin, ci, Cout, acc_ws)
+#define LWD(A, B) do { if (dtype == UNET_BF16) LW(__bf16, A, B); else LW(float, A, B); } while (0)
+        if (kh == 3 && kw == 3) LWD(3, 3);
+        else if (kh == 3 && kw == 1) LWD(3, 1);
+        else if (kh == 1 && kw == 3) LWD(1, 3);
+        else if (kh == 5 && kw == 1) LWD(5, 1);
+        else if (kh == 1 && kw == 5) LWD(1, 5);
+        else if (kh == 5 && kw == 5) LWD(5, 5);
+        else { unet_set_error("first conv wgrad: unsupported kernel %dx%d", kh, kw); return -1; }
+#undef LW
+#undef LWD
+        UNET_LAUNCH_CHECK();
+        hipLaunchKernelGGL(first_wgrad_store_kernel, dim3((Cout * NT + 255) / 256), dim3(256), 0, s, acc_ws, dw, Cout, Cin, ci, NT);
+        UNET_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+static int lanes_per_pixel(int G) { int lp = 1; while (lp < G) lp <<= 1; return lp; }
+
+extern "C" int unet_conv_out_fwd(int dtype, const void* x, int ldx, int xoff, const float* w, const float* bias, float* logits,
+                                 long long M, long long HW, int C, int K, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    UNET_CHECK(C % 8 == 0 && C / epv <= 64, "final conv: C=%d must be a multiple of 8 and at most %d", C, 64 * epv);
+    UNET_CHECK(K >= 1 && K <= 8, "final conv: n_classes must be 1..8 (got %d)", K);
+    UNET_CHECK(M % HW == 0, "final conv: M must be N*H*W");
+    const int LP = lanes_per_pixel(C / epv);
+    const int grid = grid_for(M, 256 / LP);
+    hipStream_t s = (hipStream_t)stream;
+#define LO(T, KK) hipLaunchKernelGGL((conv_out_fwd_kernel<T, KK>), dim3(grid), dim3(256), 0, s, (const T*)x, ldx, xoff, w, bias, logits, M, HW, C, LP)
+#define LOK(KK) case KK: if (dtype == UNET_BF16) LO(__bf16, KK); else LO(float, KK); break;
+    switch (K) { LOK(1) LOK(2) LOK(3) LOK(4) LOK(5) LOK(6) LOK(7) LOK(8) }
+#undef LO
+#undef LOK
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, int xoff, const float* w,
+                                 void* dx, float* dw, float* db, long long M, long long HW, int C, int K,
+                                 double* acc_ws /* K*C + K doubles */, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    UNET_CHECK(C % 8 == 0 && C / epv <= 256, "final conv bwd: bad C=%d", C);
+    UNET_CHECK(K >= 1 && K <= 8, "final conv: n_classes must be 1..8 (got %d)", K);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * (K * C + K), s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    const int PL = 256 / (C / epv);
+    const int grid = grid_for(M, PL) < 1024 ? grid_for(M, PL) : 1024;
+    const size_t lds = (size_t)256 * K * epv * sizeof(float);
+#define LB(T, KK) hipLaunchKernelGGL((conv_out_bwd_kernel<T, KK>), dim3(grid), dim3(256), lds, s, dlogits, (const T*)x, ldx, xoff, w, (T*)dx, M, HW, C, acc_ws)
+#define LBK(KK) case KK: if (dtype == UNET_BF16) LB(__bf16, KK); else LB(float, KK); break;
+    switch (K) { LBK(1) LBK(2) LBK(3) LBK(4) LBK(5) LBK(6) LBK(7) LBK(8) }
+#undef LB
+#undef LBK
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(acc_store_kernel, dim3((K * C + K + 255) / 256), dim3(256), 0, s, acc_ws, dw, K * C, db, K);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, int I, int ntaps, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    UNET_CHECK(mode >= 0 && mode <= 3, "bad pack mode %d", mode);
+    if (mode >= 2) UNET_CHECK(ntaps == 4, "convT pack needs 4 taps");
+    const size_t total = (size_t)O * I * ntaps;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UNET_BF16) hipLaunchKernelGGL((pack_weights_kernel<__bf16>), dim3(grid), dim3(256), 0, s, src, (__bf16*)dst, mode, O, I, ntaps);
+    else hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, s, src, (float*)dst, mode, O, I, ntaps);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_convT_wgrad_reduce(const float* slab, float* dw, int nsplit, int Ci, int Co, void* stream) {
+    const size_t total = (size_t)4 * Ci * Co;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, dw, nsplit, Ci, Co);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_cast(int dtype, int to_f32_dir, const void* src, void* dst, long long n, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UNET_BF16) {
+        if (to_f32_dir) hipLaunchKernelGGL((cast_to_f32_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)src, (float*)dst, (size_t)n);
+        else hipLaunchKernelGGL((cast_from_f32_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const float*)src, (__bf16*)dst, (size_t)n);
+    } else {
+        if (to_f32_dir) hipLaunchKernelGGL((cast_to_f32_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (size_t)n);
+        else hipLaunchKernelGGL((cast_from_f32_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, (size_t)n);
+    }
+    UNET_LAUNCH_CHECK();
+    return 0;
+}

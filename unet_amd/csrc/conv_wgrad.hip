@@ -1,0 +1,286 @@
+// Weight-gradient of the implicit-GEMM convolutions (gfx950), split-K over pixel tiles.
+//
+//   dW[tap][co][ci] = sum over output pixels m of  dz[m][co] * x[SH*m + tap][ci]
+//
+// i.e. a GEMM with M = Cout, N = Cin (per tap) and K = N*Hout*Wout pixels.  With NHWC storage the
+// reduction index (pixel) is the strided one, so for bf16 both MFMA operands are fetched from
+// pixel-major LDS images with the gfx950 transposing read ds_read_b64_tr_b16; the f32 path reads
+// one dword per lane for the exact f32 MFMA.
+//
+// Workgroup (4 waves): a block of 128 bytes of output channels x 128 bytes of input channels
+// (64x64 bf16, 32x32 f32) x all taps of one tap group, accumulated in registers over a contiguous
+// range of 8x32 pixel tiles; the partial block goes to slab[split][tap][co][ci] (plain stores) and
+// a second kernel sums the slabs in a fixed order (bitwise reproducible) into the OIHW gradient.
+//
+// Serves: nn.Conv2d weight grads (reference models/unet.py:10,13; reparm_unet.py:55-61) and the
+// nn.ConvTranspose2d(k=2,s=2) weight grad (models/unet.py:35) through the [N,2H,W,2C] view.
+#include "common.h"
+
+struct WgradArgs {
+    const void* dz;   // [N,Hout,Wout,lddz] (+dzoff), Cout channels
+    const void* x;    // [N,Hin,Win,ldx]   (+xoff),  Cin channels
+    float* slab;      // [nsplit][KH*KW][Cout][Cin]
+    int N, Hin, Win, Cin, ldx, xoff;
+    int Hout, Wout, Cout, lddz, dzoff;
+    int pad_h, pad_w, tiles_h, tiles_w;
+    int tiles_total, tiles_per_split;
+};
+
+// 128-byte-record LDS image: record `pix`, byte b (b<128).  The XOR keeps the eight 32-byte pieces
+// that one 32-lane half of a transposing read touches on distinct banks.
+__device__ __forceinline__ int rec128_off(int pix, int b) {
+    return pix * 128 + (b ^ ((((pix >> 1) & 1) << 6) | (((pix >> 3) & 1) << 5)));
+}
+
+template <typename T> struct WG;
+template <> struct WG<__bf16> { static constexpr int WT = 2; static constexpr int CT = 64; };   // wave tile 2x2 MFMA tiles, block 64x64
+template <> struct WG<float>  { static constexpr int WT = 1; static constexpr int CT = 32; };   // wave tile 1x1, block 32x32
+
+// A/B fragment of a 16(channel) x K(pixel) operand for one K-step.
+//   bf16: K-step = 32 pixels (pix0 .. pix0+31), two transposing reads per lane
+//   f32 : K-step = 4 pixels, one dword per lane per MFMA
+template <typename T> struct Frag;
+template <> struct Frag<__bf16> {
+    uint4 v;
+    // img: LDS image base; pix0: first pixel record of the 32-pixel K-step; chb: byte offset of the
+    // 16-channel tile inside the record (multiple of 32)
+    __device__ __forceinline__ void load(const char* img, int pix0, int chb, int lane) {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const int pa = pix0 + 8 * g + q;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rec128_off(pa, chb + 8 * p)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rec128_off(pa + 4, chb + 8 * p)));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        v = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
+};
+
+template <typename T, int KH, int KW, int SH, int TG>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int TH = 8, TW = 32;
+    constexpr int HH = (TH - 1) * SH + KH, HWD = TW - 1 + KW;
+    constexpr int EPV = TT<T>::EPV;
+    constexpr int CT = WG<T>::CT, WT = WG<T>::WT;
+    constexpr int NTAPS = KH * KW;
+    constexpr int DZ_BYTES = TH * TW * 128, HALO_PIX = HH * HWD;
+    constexpr int DZ_UNITS = TH * TW * 8, HALO_UNITS = HALO_PIX * 8;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_dz = smem;
+    char* s_x = smem + DZ_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int split = blockIdx.x;
+    const int co0 = blockIdx.y * CT, ci0 = blockIdx.z * CT;
+    const int wco = (wave >> 1) * (16 * WT), wci = (wave & 1) * (16 * WT);   // wave's corner inside the block tile
+
+    f32x4 acc[TG][WT][WT];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ dzp = (const T*)a.dz;
+    const T* __restrict__ xp = (const T*)a.x;
+
+    const int t_begin = split * a.tiles_per_split;
+    const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        int t = tile;
+        const int tw_i = t % a.tiles_w; t /= a.tiles_w;
+        const int th_i = t % a.tiles_h;
+        const int n = t / a.tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * TW;
+
+        __syncthreads();   // previous tile's reads are done
+        // ---- stage dz tile: 256 pixels x 128 bytes ----
+        {
+            const T* base = dzp + (size_t)n * a.Hout * a.Wout * a.lddz + a.dzoff + co0;
+            for (int u = tid; u < DZ_UNITS; u += 256) {
+                const int pix = u >> 3, q = u & 7;
+                const int r = pix >> 5, c = pix & 31;
+                const int ho = h0 + r, wo = w0 + c;
+                const bool ok = ho < a.Hout && wo < a.Wout && (co0 + q * EPV) < a.Cout;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *(const uint4*)(base + ((size_t)ho * a.Wout + wo) * a.lddz + q * EPV);
+                *(uint4*)(s_dz + rec128_off(pix, q * 16)) = v;
+            }
+        }
+        // ---- stage x halo: HH x HWD pixels x 128 bytes ----
+        {
+            const T* base = xp + (size_t)n * a.Hin * a.Win * a.ldx + a.xoff + ci0;
+            for (int u = tid; u < HALO_UNITS; u += 256) {
+                const int pix = u >> 3, q = u & 7;
+                const int hr = pix / HWD, hc = pix - hr * HWD;
+                const int row = h0 * SH + hr - a.pad_h, col = w0 + hc - a.pad_w;
+                const bool ok = row >= 0 && row < a.Hin && col >= 0 && col < a.Win && (ci0 + q * EPV) < a.Cin;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (ok) v = *(const uint4*)(base + ((size_t)row * a.Win + col) * a.ldx + q * EPV);
+                *(uint4*)(s_x + rec128_off(pix, q * 16)) = v;
+            }
+        }
+        __syncthreads();
+
+        if constexpr (sizeof(T) == 2) {
+            // K-step = one tile row (32 pixels)
+#pragma unroll 1
+            for (int r = 0; r < TH; ++r) {
+                Frag<__bf16> fa[WT];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) fa[i].load(s_dz, r * 32, (wco + 16 * i) * 2, lane);
+#pragma unroll
+                for (int t2 = 0; t2 < TG; ++t2) {
+                    const int kh = t2 / KW, kw = t2 % KW;
+                    Frag<__bf16> fb[WT];
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) fb[j].load(s_x, (r * SH + kh) * HWD + kw, (wci + 16 * j) * 2, lane);
+#pragma unroll
+                    for (int i = 0; i < WT; ++i)
+#pragma unroll
+                        for (int j = 0; j < WT; ++j)
+                            acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fa[i].v), __builtin_bit_cast(bf16x8, fb[j].v), acc[t2][i][j], 0, 0, 0);
+                }
+            }
+        } else {
+            // K-step = 4 pixels; A[row=l15][k=g] = dz[pix+g][co], B[k=g][col=l15] = x[pix'+g][ci]
+#pragma unroll 1
+            for (int r = 0; r < TH; ++r) {
+#pragma unroll 1
+                for (int c4 = 0; c4 < TW; c4 += 4) {
+                    const float av = *(const float*)(s_dz + rec128_off(r * 32 + c4 + g, (wco + l15) * 4));
+#pragma unroll
+                    for (int t2 = 0; t2 < TG; ++t2) {
+                        const int kh = t2 / KW, kw = t2 % KW;
+                        const float bv = *(const float*)(s_x + rec128_off((r * SH + kh) * HWD + kw + c4 + g, (wci + l15) * 4));
+                        acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t2][0][0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- store the partial block: D[row = co = 4g+reg][col = ci = l15] ----
+    float* slab = a.slab + (size_t)split * NTAPS * a.Cout * a.Cin;
+#pragma unroll
+    for (int t2 = 0; t2 < TG; ++t2)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int ci = ci0 + wci + 16 * j + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wco + 16 * i + 4 * g + r;
+                    if (co < a.Cout && ci < a.Cin) slab[((size_t)t2 * a.Cout + co) * a.Cin + ci] = acc[t2][i][j][r];
+                }
+            }
+}
+
+// Sum split-K slabs in split order and scatter to the framework layout:
+//   out[o][i][tap] (= OIHW for Conv2d, (Cin,Cout,kh,kw) for ConvTranspose2d) = sum_s slab[s][tap][o][i]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                    int nsplit, int ntaps, int O, int I, int accumulate,
+                                    int out_taps, int out_tap0) {
+    const size_t total = (size_t)ntaps * O * I;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + e];
+        const int i = (int)(e % I);
+        const size_t r = e / I;
+        const int o = (int)(r % O);
+        const int tap = (int)(r / O);
+        const size_t dst = ((size_t)o * I + i) * out_taps + out_tap0 + tap;
+        out[dst] = accumulate ? out[dst] + s : s;
+    }
+}
+
+template <typename T, int KH, int KW, int SH>
+static int launch_wgrad(const WgradArgs& a, hipStream_t stream, int nsplit) {
+    constexpr int TG = KH * KW;
+    constexpr int HH = 7 * SH + KH, HWD = 31 + KW;
+    constexpr int SMEM = 8 * 32 * 128 + HH * HWD * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, KH, KW, SH, TG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", SMEM, hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    constexpr int CT = WG<T>::CT;
+    dim3 grid((unsigned)nsplit, (unsigned)((a.Cout + CT - 1) / CT), (unsigned)((a.Cin + CT - 1) / CT));
+    hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, SH, TG>), grid, dim3(256), SMEM, stream, a);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+template <typename T>
+static int dispatch_wgrad(int kh, int kw, int sh, const WgradArgs& a, hipStream_t s, int nsplit) {
+    if (sh == 2) {
+        UNET_CHECK(kh == 2 && kw == 1, "stride-2 form is the 2x1 convT view only");
+        return launch_wgrad<T, 2, 1, 2>(a, s, nsplit);
+    }
+    if (kh == 3 && kw == 3) return launch_wgrad<T, 3, 3, 1>(a, s, nsplit);
+    if (kh == 1 && kw == 1) return launch_wgrad<T, 1, 1, 1>(a, s, nsplit);
+    if (kh == 3 && kw == 1) return launch_wgrad<T, 3, 1, 1>(a, s, nsplit);
+    if (kh == 1 && kw == 3) return launch_wgrad<T, 1, 3, 1>(a, s, nsplit);
+    if (kh == 5 && kw == 1) return launch_wgrad<T, 5, 1, 1>(a, s, nsplit);
+    if (kh == 1 && kw == 5) return launch_wgrad<T, 1, 5, 1>(a, s, nsplit);
+    unet_set_error("unsupported wgrad kernel %dx%d stride %d", kh, kw, sh);
+    return -1;
+}
+
+// Number of split-K slabs unet_conv_wgrad will write for this problem (the caller sizes the
+// workspace as nsplit * kh*kw * Cout * Cin floats).
+extern "C" int unet_conv_wgrad_splits(int dtype, int N, int Hout, int Wout, int Cin, int Cout) {
+    const int ct = dtype == UNET_BF16 ? 64 : 32;
+    const int tiles = N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
+    const int blocks = ((Cout + ct - 1) / ct) * ((Cin + ct - 1) / ct);
+    int want = (1024 + blocks - 1) / blocks;          // aim for ~4 workgroups per CU
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const int per = (tiles + want - 1) / want;
+    return (tiles + per - 1) / per;
+}
+
+extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
+                               const void* dz, const void* x, float* slab, float* dw, int accumulate,
+                               int dw_taps, int dw_tap0,
+                               int N, int Hin, int Win, int Cin, int ldx, int xoff,
+                               int Hout, int Wout, int Cout, int lddz, int dzoff,
+                               int pad_h, int pad_w, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    UNET_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddz % 8 == 0 && dzoff % 8 == 0,
+               "channel counts/strides/offsets must be multiples of 8");
+    UNET_CHECK(xoff + Cin <= ldx && dzoff + Cout <= lddz, "channel slice exceeds pixel stride");
+    // pad_h/pad_w may be any integers: a 5x5 weight grad is issued as five 1x5 launches with
+    // pad_h = 2 - row, each filling taps [dw_tap0, dw_tap0 + kh*kw) of the dw_taps-tap gradient
+    UNET_CHECK(kh * kw <= 9, "wgrad handles at most 9 taps per launch; split larger kernels by rows");
+    UNET_CHECK(dw_tap0 >= 0 && dw_tap0 + kh * kw <= dw_taps, "tap window outside the gradient tensor");
+    UNET_CHECK(N > 0 && Hout > 0 && Wout > 0, "empty wgrad problem");
+    UNET_CHECK((size_t)Hin * Win * ldx < (1ull << 31) && (size_t)Hout * Wout * lddz < (1ull << 31), "image exceeds 2^31 elements");
+    WgradArgs a;
+    a.dz = dz; a.x = x; a.slab = slab;
+    a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.ldx = ldx; a.xoff = xoff;
+    a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.lddz = lddz; a.dzoff = dzoff;
+    a.pad_h = pad_h; a.pad_w = pad_w;
+    a.tiles_h = (Hout + 7) / 8; a.tiles_w = (Wout + 31) / 32;
+    a.tiles_total = N * a.tiles_h * a.tiles_w;
+    const int nsplit = unet_conv_wgrad_splits(dtype, N, Hout, Wout, Cin, Cout);
+    a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = dtype == UNET_BF16 ? dispatch_wgrad<__bf16>(kh, kw, stride_h, a, s, nsplit)
+                                : dispatch_wgrad<float>(kh, kw, stride_h, a, s, nsplit);
+    if (rc) return rc;
+    if (dw == nullptr) return 0;    // caller reduces the slabs itself (ConvTranspose2d layout)
+    const size_t total = (size_t)kh * kw * Cout * Cin;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, nsplit, kh * kw, Cout, Cin, accumulate, dw_taps, dw_tap0);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,514 @@
+// Bandwidth-bound NHWC kernels of the U-Net hot path (gfx950): BatchNorm statistics / apply /
+// backward fused with ReLU, and 2x2 max-pool with a 2-bit argmax code.
+//
+// Thread mapping shared by every per-channel kernel here: a thread owns ONE 16-byte channel group
+// (8 bf16 / 4 f32 channels) and walks pixels; a 256-thread workgroup covers PL = 256/G pixels x
+// G = C/EPV groups, so consecutive lanes read consecutive 16-byte vectors (fully coalesced) and
+// per-channel constants live in registers.
+//
+// Reference semantics followed: nn.BatchNorm2d + nn.ReLU(inplace) in DoubleConv
+// (/root/reference/models/unet.py:11-12,14-15) and nn.MaxPool2d(2,2) (models/unet.py:26,47).
+#include "common.h"
+
+#define MAX_GRID 2048
+
+struct ChanMap {
+    int G, PL, pl, cg;
+    bool active;
+    template <typename T> __device__ __forceinline__ void init(int C) {
+        G = C / TT<T>::EPV;
+        PL = 256 / G;
+        pl = threadIdx.x / G;
+        cg = threadIdx.x - pl * G;
+        active = pl < PL;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// BN statistics: reduce the conv epilogue's per-tile (sum, sumsq) rows into fp64 totals.
+// grid (ceil(C/32), S); rows [nrows][C][2] fp32; acc [C][2] fp64 (zeroed by the launcher).
+__global__ void bn_stats_reduce_kernel(const float* __restrict__ rows, int nrows, int C, double* __restrict__ acc) {
+    const int ch = threadIdx.x & 31, pl = threadIdx.x >> 5;     // 32 channels x 8 row lanes
+    const int c = blockIdx.x * 32 + ch;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int r = blockIdx.y * 8 + pl; r < nrows; r += gridDim.y * 8) {
+            const float2 v = *(const float2*)(rows + ((size_t)r * C + c) * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+    __shared__ double red[8][32][2];
+    red[pl][ch][0] = s1;
+    red[pl][ch][1] = s2;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ch2 = threadIdx.x >> 1, k = threadIdx.x & 1;
+        double s = 0.0;
+        for (int p = 0; p < 8; ++p) s += red[p][ch2][k];
+        const int c2 = blockIdx.x * 32 + ch2;
+        if (c2 < C) atomicAdd(&acc[c2 * 2 + k], s);
+    }
+}
+
+// One thread per channel: batch mean / biased var -> (scale, shift, mean, invstd) and the running
+// statistics update r = (1-m) r + m stat with UNBIASED variance, num_batches_tracked += 1.
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ nbt, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt != nullptr) *nbt += 1;
+    if (c >= C) return;
+    const double mean = acc[c * 2] / count;
+    double var = acc[c * 2 + 1] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    if (running_mean != nullptr) {
+        const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+// eval mode: coefficients from the running statistics
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// y = relu(z*scale + shift)   (relu optional)
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z, int ldz, int zoff,
+                                                         T* __restrict__ y, int ldy, int yoff,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         long long M, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(C);
+    if (!m.active) return;
+    float sc[EPV], sh[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { sc[e] = scale[m.cg * EPV + e]; sh[e] = shift[m.cg * EPV + e]; }
+    for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+        const uint4 v = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
+        float f[EPV];
+        Vec16<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            f[e] = fmaf(f[e], sc[e], sh[e]);
+            if (RELU) f[e] = fmaxf(f[e], 0.f);
+        }
+        *(uint4*)(y + p * ldy + yoff + m.cg * EPV) = Vec16<T>::pack(f);
+    }
+}
+
+// Block-level reduction of per-thread [NV] partials over the PL pixel lanes, then fp64 atomics.
+template <int NV>
+__device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const float (&part)[NV], int epv, int C,
+                                                    double* acc, int acc_stride /* values per channel */) {
+    // layout in LDS: [pl][cg][NV]
+    extern __shared__ float red_lds[];
+    if (m.active) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red_lds[(m.pl * m.G + m.cg) * NV + i] = part[i];
+    }
+    __syncthreads();
+    const int per_block = m.G * NV;                  // values after reducing over pl
+    for (int i = threadIdx.x; i < per_block; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < m.PL; ++p) s += red_lds[p * per_block + i];
+        // i = cg*NV + (k*epv + e): value k of channel cg*epv+e
+        const int cg = i / NV, r = i - cg * NV;
+        const int k = r / epv, e = r - k * epv;
+        const int c = cg * epv + e;
+        if (c < C) atomicAdd(&acc[c * acc_stride + k], (double)s);
+    }
+}
+
+// BN+ReLU backward, pass 1: S1 = sum dy', S2 = sum dy' * xhat with dy' = dy * [z*scale+shift > 0]
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int ldd, int doff,
+                                                            const T* __restrict__ z, int ldz, int zoff,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            long long M, int C, double* __restrict__ acc) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(C);
+    float part[2 * EPV];
+#pragma unroll
+    for (int i = 0; i < 2 * EPV; ++i) part[i] = 0.f;
+    if (m.active) {
+        float sc[EPV], sh[EPV], mu[EPV], is[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = m.cg * EPV + e;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+        }
+        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+            float fz[EPV], fd[EPV];
+            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
+            Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + m.cg * EPV), fd);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                part[e] += d;
+                part[EPV + e] += d * ((fz[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+    block_reduce_to_acc<2 * EPV>(m, part, EPV, C, acc, 2);
+}
+
+// pass 1 finalize: dgamma = S2, dbeta = S1, c1 = S1/n, c2 = S2/n
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, double count, int C,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ c1, float* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double s1 = acc[c * 2], s2 = acc[c * 2 + 1];
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+    c1[c] = (float)(s1 / count);
+    c2[c] = (float)(s2 / count);
+}
+
+// pass 2: dz = scale_g * (dy' - c1 - xhat*c2) with scale_g = gamma*invstd (= forward scale);
+// also accumulates sum(dz) per channel (the bias gradient of the conv in front of the BN).
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int ldd, int doff,
+                                                           const T* __restrict__ z, int ldz, int zoff,
+                                                           T* __restrict__ dz, int ldo, int ooff,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           long long M, int C, double* __restrict__ dbias_acc) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(C);
+    float part[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) part[i] = 0.f;
+    if (m.active) {
+        float sc[EPV], sh[EPV], mu[EPV], is[EPV], k1[EPV], k2[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = m.cg * EPV + e;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; k1[e] = c1[c]; k2[e] = c2[c];
+        }
+        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+            float fz[EPV], fd[EPV];
+            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
+            Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + m.cg * EPV), fd);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                const float xh = (fz[e] - mu[e]) * is[e];
+                fd[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+            }
+            const uint4 o = Vec16<T>::pack(fd);
+            *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = o;
+            if (dbias_acc != nullptr) {
+                float fr[EPV];
+                Vec16<T>::unpack(o, fr);          // sum what the consumers of dz will actually read
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+            }
+        }
+    }
+    if (dbias_acc != nullptr) block_reduce_to_acc<EPV>(m, part, EPV, C, dbias_acc, 1);
+}
+
+// plain ReLU backward (no norm): dz = dy * [y > 0]   (RepUNet: ReLU after the branch sum)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, int ldd, int doff,
+                                                       const T* __restrict__ y, int ldy, int yoff,
+                                                       T* __restrict__ dz, int ldo, int ooff, long long M, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(C);
+    if (!m.active) return;
+    for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+        float fy[EPV], fd[EPV];
+        Vec16<T>::unpack(*(const uint4*)(y + p * ldy + yoff + m.cg * EPV), fy);
+        Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + m.cg * EPV), fd);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) fd[e] = fy[e] > 0.f ? fd[e] : 0.f;
+        *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = Vec16<T>::pack(fd);
+    }
+}
+
+// per-channel sum over pixels -> fp64 acc[C] (bias gradient of ConvTranspose2d and friends)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, int ldx, int xoff, long long M, int C,
+                                                          double* __restrict__ acc) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(C);
+    float part[EPV];
+#pragma unroll
+    for (int i = 0; i < EPV; ++i) part[i] = 0.f;
+    if (m.active) {
+        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+            float f[EPV];
+            Vec16<T>::unpack(*(const uint4*)(x + p * ldx + xoff + m.cg * EPV), f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) part[e] += f[e];
+        }
+    }
+    block_reduce_to_acc<EPV>(m, part, EPV, C, acc, 1);
+}
+
+__global__ void acc_to_f32_kernel(const double* __restrict__ acc, float* __restrict__ out, int n, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = accumulate ? out[i] + (float)acc[i] : (float)acc[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x2 / stride-2 max-pool with argmax.  code = 2*dh + dw of the winner; ATen CPU rule
+// (max_pool2d_with_indices): scan the window row-major from -inf, take v if (v > max) || isnan(v).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int ldx, int xoff,
+                                                          T* __restrict__ y, uint8_t* __restrict__ code,
+                                                          int N, int H, int W, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV, Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)N * Ho * Wo * G;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+        const int cg = (int)(v % G);
+        long long p = v / G;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const T* base = x + (((long long)n * H + 2 * ho) * W + 2 * wo) * ldx + xoff + cg * EPV;
+        float best[EPV];
+        unsigned cd[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { best[e] = -INFINITY; cd[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[EPV];
+            Vec16<T>::unpack(*(const uint4*)(base + ((long long)(k >> 1) * W + (k & 1)) * ldx), f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e)
+                if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; cd[e] = k; }
+        }
+        const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + cg * EPV;
+        *(uint4*)(y + o) = Vec16<T>::pack(best);
+        if (EPV == 8) {
+            uint2 pk;
+            pk.x = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+            pk.y = cd[4 % EPV] | (cd[5 % EPV] << 8) | (cd[6 % EPV] << 16) | (cd[7 % EPV] << 24);
+            *(uint2*)(code + o) = pk;
+        } else {
+            *(uint32_t*)(code + o) = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+        }
+    }
+}
+
+// dx[n,2ho+dh,2wo+dw,c] = (skip ? dskip[...] : 0) + (code == 2dh+dw ? dy[n,ho,wo,c] : 0)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ code,
+                                                          const T* __restrict__ dskip, int lds_, int soff,
+                                                          T* __restrict__ dx, int N, int H, int W, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV, Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)N * Ho * Wo * G;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+        const int cg = (int)(v % G);
+        long long p = v / G;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + cg * EPV;
+        float g[EPV];
+        Vec16<T>::unpack(*(const uint4*)(dy + o), g);
+        unsigned cd[8];
+        if (EPV == 8) {
+            const uint2 pk = *(const uint2*)(code + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cd[e] = (pk.x >> (8 * e)) & 0xff; cd[4 + e] = (pk.y >> (8 * e)) & 0xff; }
+        } else {
+            const uint32_t pk = *(const uint32_t*)(code + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cd[e] = (pk >> (8 * e)) & 0xff;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long pix = ((long long)n * H + 2 * ho + (k >> 1)) * W + 2 * wo + (k & 1);
+            float f[EPV];
+            if (dskip != nullptr) Vec16<T>::unpack(*(const uint4*)(dskip + pix * lds_ + soff + cg * EPV), f);
+            else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) f[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] += (cd[e] == (unsigned)k) ? g[e] : 0.f;
+            *(uint4*)(dx + pix * C + cg * EPV) = Vec16<T>::pack(f);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static inline int grid_for(long long M, int PL) {
+    long long g = (M + PL - 1) / PL;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static inline int chan_check(int dtype, int C, const char* what) {
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    if (dtype != UNET_F32 && dtype != UNET_BF16) { unet_set_error("%s: bad dtype %d", what, dtype); return -1; }
+    if (C <= 0 || C % 8 != 0 || C / epv > 256) { unet_set_error("%s: C=%d must be a multiple of 8 and at most %d", what, C, 256 * epv); return -1; }
+    return 0;
+}
+
+extern "C" int unet_bn_finalize(const float* stat_rows, int nrows, int C, long long count,
+                                const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                float momentum, float eps,
+                                float* scale, float* shift, float* mean, float* invstd,
+                                double* acc_ws /* 2*C doubles */, void* stream) {
+    UNET_CHECK(nrows > 0 && C > 0 && count > 0, "bn_finalize: empty problem");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    int S = (nrows + 63) / 64; if (S > 64) S = 64; if (S < 1) S = 1;
+    hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((C + 31) / 32, S), dim3(256), 0, s, stat_rows, nrows, C, acc_ws);
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)count, C, gamma, beta,
+                       running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* scale, float* shift, void* stream) {
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                       running_mean, running_var, eps, scale, shift);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_affine_act(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
+                               const float* scale, const float* shift, long long M, int C, void* stream) {
+    if (chan_check(dtype, C, "affine_act")) return -1;
+    UNET_CHECK(ldz % 8 == 0 && zoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0, "affine_act: strides/offsets must be multiples of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    const int grid = grid_for(M, PL);
+#define LAUNCH_AA(T, R) hipLaunchKernelGGL((affine_act_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)z, ldz, zoff, (T*)y, ldy, yoff, scale, shift, M, C)
+    if (dtype == UNET_BF16) { if (relu) LAUNCH_AA(__bf16, true); else LAUNCH_AA(__bf16, false); }
+    else { if (relu) LAUNCH_AA(float, true); else LAUNCH_AA(float, false); }
+#undef LAUNCH_AA
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                                void* dz, int ldo, int ooff,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* dbias /* nullable */,
+                                float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
+                                long long M, int C, void* stream) {
+    if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
+    UNET_CHECK(ldd % 8 == 0 && doff % 8 == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0,
+               "bn_relu_bwd: strides/offsets must be multiples of 8");
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    const int grid = grid_for(M, PL);
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    const size_t lds1 = (size_t)256 * 2 * epv * sizeof(float), lds2 = (size_t)256 * epv * sizeof(float);
+    float* c1 = c1c2_ws; float* c2 = c1c2_ws + C;
+    double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
+#define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), dim3(grid), dim3(256), lds1, s, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
+#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), dim3(grid), dim3(256), lds2, s, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, c1, c2, M, C, dbacc)
+    if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
+    else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)M, C, dgamma, dbeta, c1, c2);
+    UNET_LAUNCH_CHECK();
+    if (dtype == UNET_BF16) { if (relu) LAUNCH_A(__bf16, true); else LAUNCH_A(__bf16, false); }
+    else { if (relu) LAUNCH_A(float, true); else LAUNCH_A(float, false); }
+    UNET_LAUNCH_CHECK();
+#undef LAUNCH_R
+#undef LAUNCH_A
+    if (dbias) {
+        hipLaunchKernelGGL(acc_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws + 2 * C, dbias, C, 0);
+        UNET_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int unet_relu_bwd(int dtype, const void* dy, int ldd, int doff, const void* y, int ldy, int yoff,
+                             void* dz, int ldo, int ooff, long long M, int C, void* stream) {
+    if (chan_check(dtype, C, "relu_bwd")) return -1;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    const int grid = grid_for(M, PL);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UNET_BF16)
+        hipLaunchKernelGGL((relu_bwd_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)dy, ldd, doff, (const __bf16*)y, ldy, yoff, (__bf16*)dz, ldo, ooff, M, C);
+    else
+        hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dy, ldd, doff, (const float*)y, ldy, yoff, (float*)dz, ldo, ooff, M, C);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, long long M, int C, float* out, int accumulate,
+                                double* acc_ws /* C doubles */, void* stream) {
+    if (chan_check(dtype, C, "channel_sum")) return -1;
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    const int grid = grid_for(M, PL);
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    const size_t lds = (size_t)256 * epv * sizeof(float);
+    if (dtype == UNET_BF16)
+        hipLaunchKernelGGL((channel_sum_kernel<__bf16>), dim3(grid), dim3(256), lds, s, (const __bf16*)x, ldx, xoff, M, C, acc_ws);
+    else
+        hipLaunchKernelGGL((channel_sum_kernel<float>), dim3(grid), dim3(256), lds, s, (const float*)x, ldx, xoff, M, C, acc_ws);
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(acc_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, out, C, accumulate);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_maxpool2x2_fwd(int dtype, const void* x, int ldx, int xoff, void* y, uint8_t* code,
+                                   int N, int H, int W, int C, void* stream) {
+    if (chan_check(dtype, C, "maxpool_fwd")) return -1;
+    UNET_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "maxpool: H and W must be even (got %dx%d)", H, W);
+    UNET_CHECK(ldx % 8 == 0 && xoff % 8 == 0, "maxpool: stride/offset must be multiples of 8");
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / epv);
+    const int grid = grid_for(total, 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UNET_BF16)
+        hipLaunchKernelGGL((maxpool_fwd_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)x, ldx, xoff, (__bf16*)y, code, N, H, W, C);
+    else
+        hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)x, ldx, xoff, (float*)y, code, N, H, W, C);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_maxpool2x2_bwd(int dtype, const void* dy, const uint8_t* code, const void* dskip, int lds_, int soff,
+                                   void* dx, int N, int H, int W, int C, void* stream) {
+    if (chan_check(dtype, C, "maxpool_bwd")) return -1;
+    UNET_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "maxpool: H and W must be even (got %dx%d)", H, W);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / epv);
+    const int grid = grid_for(total, 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == UNET_BF16)
+        hipLaunchKernelGGL((maxpool_bwd_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)dy, code, (const __bf16*)dskip, lds_, soff, (__bf16*)dx, N, H, W, C);
+    else
+        hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dy, code, (const float*)dskip, lds_, soff, (float*)dx, N, H, W, C);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,234 @@
+"""Forward / backward schedule of the U-Net on the HIP kernels (one autograd node per model call).
+
+Follows the reference wiring (/root/reference/models/unet.py:41-62): 4x [DoubleConv, MaxPool] ->
+bottleneck -> 4x [ConvTranspose2d, cat(skip, up), DoubleConv] -> 1x1 conv.  Differences that are
+invisible to the caller:
+  * activations are NHWC in the compute dtype (bf16 under autocast / amp, else fp32);
+  * torch.cat is designed away: the encoder's second BN+ReLU and the transposed conv both write into
+    one pre-allocated 2f-channel buffer (skip first, as models/unet.py:59);
+  * BN batch statistics come from the conv epilogue; pool saves a 2-bit argmax code;
+  * backward is an explicit schedule; parameter gradients are produced in backward-arrival order and
+    handed to `grad_hook(names, tensors)` as soon as they are enqueued (data-parallel bucketing).
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .ops import Act, Workspace
+
+BN_EPS = 1e-5
+
+
+class _Saved:
+    pass
+
+
+def _double_conv_names(prefix):
+    return [f"{prefix}.double_conv.{i}.{k}" for i, ks in ((0, ("weight", "bias")), (1, ("weight", "bias")),
+                                                          (3, ("weight", "bias")), (4, ("weight", "bias"))) for k in ks]
+
+
+class UNetEngine:
+    """Executes UNet forward/backward for a module that owns reference-layout parameters."""
+
+    def __init__(self, features, in_channels, n_classes):
+        self.features = list(features)
+        self.in_channels = in_channels
+        self.n_classes = n_classes
+        self._ws: Dict[torch.device, Workspace] = {}
+        self._packed = {}       # (name, mode, dt) -> (version, tensor)
+
+    # ------------------------------------------------------------------ helpers
+    def ws(self, device) -> Workspace:
+        w = self._ws.get(device)
+        if w is None:
+            w = self._ws[device] = Workspace(device)
+        return w
+
+    def packed(self, name, p: torch.Tensor, mode, dt):
+        key = (name, mode, dt)
+        ver = (p._version, p.data_ptr())
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        t = ops.pack_weights(p, mode, dt)
+        self._packed[key] = (ver, t)
+        return t
+
+    # ------------------------------------------------------------------ forward
+    def _conv_bn_relu(self, P, B, prefix, idx, xin, yout: Optional[Act], dt, train, save, first=False, x_f32=None):
+        """conv3x3(+bias) -> BN -> ReLU.  Returns (y Act, saved record)."""
+        wname, bname = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx}.bias"
+        bnp = f"{prefix}.double_conv.{idx + 1}"
+        w, b = P[wname], P[bname]
+        Cout = w.shape[0]
+        dev = w.device
+        ws = self.ws(dev)
+        if first:
+            N, H, W_, _ = x_f32.shape
+            z = ops.dense(N, H, W_, Cout, dt, dev)
+            rows = ops.conv_first_fwd(x_f32, w.detach(), b.detach(), z, 3, 3, stats=train)
+        else:
+            Cin = w.shape[1]
+            z = ops.dense(xin.N, xin.H, xin.W, Cout, dt, dev)
+            rows = ops.conv_fwd(xin, self.packed(wname, w, 0, dt), b.detach(), z, 3, 3, Cin, Cout, stats=train)
+        gamma, beta = P[bnp + ".weight"].detach(), P[bnp + ".bias"].detach()
+        if train:
+            st = ops.bn_finalize(rows, z.M, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
+                                 B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
+        else:
+            st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS)
+        y = yout if yout is not None else ops.dense(z.N, z.H, z.W, Cout, dt, dev)
+        ops.affine_act(z, y, st, relu=True)
+        rec = None
+        if save:
+            rec = _Saved()
+            rec.xin, rec.x_f32, rec.z, rec.st, rec.first = xin, x_f32, z, st, first
+            rec.wname, rec.bname, rec.bnp = wname, bname, bnp
+        return y, rec
+
+    def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], B: Dict[str, torch.Tensor], dt: int,
+                train: bool, save: bool):
+        """x: fp32 NCHW [N,Cin,H,W] on the GPU.  Returns (logits fp32 NCHW, saved state or None)."""
+        if not x.is_cuda:
+            raise ops.UNetHipError("unet_amd.UNet runs on MI355X only (input is a CPU tensor; there is no CPU fallback)")
+        N, Cin, H, W = x.shape
+        L = len(self.features)
+        if Cin != self.in_channels:
+            raise ops.UNetHipError(f"expected {self.in_channels} input channels, got {Cin}")
+        if H % (1 << L) or W % (1 << L):
+            # the reference falls into a bilinear-resize branch here (models/unet.py:56-57); not built
+            raise ops.UNetHipError(f"H and W must be divisible by {1 << L} (got {H}x{W})")
+        dev = x.device
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        x_nhwc = x.contiguous() if Cin == 1 else x.permute(0, 2, 3, 1).contiguous()
+        x_nhwc = x_nhwc.view(N, H, W, Cin)
+        sv = _Saved() if save else None
+        if save:
+            sv.blocks, sv.codes, sv.cats, sv.up_in = {}, [], [], []
+            sv.dt, sv.shape = dt, (N, H, W)
+
+        cats: List[torch.Tensor] = []
+        cur: Optional[Act] = None
+        h, w = H, W
+        for i, f in enumerate(self.features):
+            cat = torch.empty((N, h, w, 2 * f), dtype=ops.torch_dtype(dt), device=dev)
+            cats.append(cat)
+            p = f"downs.{i}"
+            y1, r1 = self._conv_bn_relu(P, B, p, 0, cur, None, dt, train, save, first=(i == 0), x_f32=x_nhwc if i == 0 else None)
+            skip = Act(cat, 0, f)
+            y2, r2 = self._conv_bn_relu(P, B, p, 3, y1, skip, dt, train, save)
+            if save:
+                r2.xin = y1
+                sv.blocks[p] = (r1, r2)
+            cur, code = ops.maxpool_fwd(skip)
+            if save:
+                sv.codes.append(code)
+            h, w = h // 2, w // 2
+        y1, r1 = self._conv_bn_relu(P, B, "bottleneck", 0, cur, None, dt, train, save)
+        cur, r2 = self._conv_bn_relu(P, B, "bottleneck", 3, y1, None, dt, train, save)
+        if save:
+            sv.blocks["bottleneck"] = (r1, r2)
+        for j, f in enumerate(reversed(self.features)):
+            cat = cats[L - 1 - j]
+            wt, bt = P[f"ups.{2 * j}.weight"], P[f"ups.{2 * j}.bias"]
+            if save:
+                sv.up_in.append(cur)
+            # ConvTranspose2d(2f -> f, k2, s2) as GEMM + pixel shuffle into cat[..., f:2f]
+            ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), Act(cat, f, f), 1, 1,
+                         2 * f, 4 * f, epi=1)
+            p = f"ups.{2 * j + 1}"
+            y1, r1 = self._conv_bn_relu(P, B, p, 0, Act(cat, 0, 2 * f), None, dt, train, save)
+            cur, r2 = self._conv_bn_relu(P, B, p, 3, y1, None, dt, train, save)
+            if save:
+                sv.blocks[p] = (r1, r2)
+        logits = ops.conv_out_fwd(cur, P["final_conv.weight"].detach().view(self.n_classes, -1).contiguous(),
+                                  P["final_conv.bias"].detach())
+        if save:
+            sv.last, sv.cats = cur, cats
+        return logits, sv
+
+    # ------------------------------------------------------------------ backward
+    def _block_bwd(self, P, sv, prefix, dy: Act, grads: Dict[str, torch.Tensor], dt, need_dx=True,
+                   split_f: int = 0):
+        """Backward of one DoubleConv.  Returns dx (Act), or (dskip, dup) when split_f > 0."""
+        r1, r2 = sv.blocks[prefix]
+        dev = dy.buf.device
+        ws = self.ws(dev)
+        # second conv
+        z2 = r2.z
+        dz2 = ops.dense(z2.N, z2.H, z2.W, z2.C, dt, dev)
+        dg, db_, dbias = ops.bn_relu_bwd(dy, z2, dz2, r2.st, ws)
+        grads[r2.bnp + ".weight"], grads[r2.bnp + ".bias"], grads[r2.bname] = dg, db_, dbias
+        w2 = P[r2.wname]
+        grads[r2.wname] = ops.conv_wgrad(dz2, r2.xin, 3, 3, ws)[0].view_as(w2)
+        dy1 = ops.dense(z2.N, z2.H, z2.W, w2.shape[1], dt, dev)
+        ops.conv_fwd(dz2, self.packed(r2.wname, w2, 1, dt), None, dy1, 3, 3, w2.shape[0], w2.shape[1])
+        del dz2
+        # first conv
+        z1 = r1.z
+        dz1 = ops.dense(z1.N, z1.H, z1.W, z1.C, dt, dev)
+        dg, db_, dbias = ops.bn_relu_bwd(dy1, z1, dz1, r1.st, ws)
+        grads[r1.bnp + ".weight"], grads[r1.bnp + ".bias"], grads[r1.bname] = dg, db_, dbias
+        del dy1
+        w1 = P[r1.wname]
+        if r1.first:
+            grads[r1.wname] = ops.conv_first_wgrad(dz1, r1.x_f32, 3, 3, ws)
+            return None
+        grads[r1.wname] = ops.conv_wgrad(dz1, r1.xin, 3, 3, ws)[0].view_as(w1)
+        if not need_dx:
+            return None
+        Cin = w1.shape[1]
+        wd = self.packed(r1.wname, w1, 1, dt)
+        if split_f:
+            dskip = ops.dense(z1.N, z1.H, z1.W, split_f, dt, dev)
+            dup = ops.dense(z1.N, z1.H, z1.W, Cin - split_f, dt, dev)
+            ops.conv_fwd(dz1, wd, None, dskip, 3, 3, w1.shape[0], Cin, y2=dup, csplit=split_f)
+            return dskip, dup
+        dx = ops.dense(z1.N, z1.H, z1.W, Cin, dt, dev)
+        ops.conv_fwd(dz1, wd, None, dx, 3, 3, w1.shape[0], Cin)
+        return dx
+
+    def backward(self, dlogits: torch.Tensor, P: Dict[str, torch.Tensor], sv,
+                 grad_hook: Optional[Callable[[List[str]], None]] = None) -> Dict[str, torch.Tensor]:
+        dt = sv.dt
+        L = len(self.features)
+        dev = dlogits.device
+        ws = self.ws(dev)
+        grads: Dict[str, torch.Tensor] = {}
+
+        def emit(names):
+            if grad_hook is not None:
+                grad_hook(names, [grads[n] for n in names])
+
+        dlogits = dlogits.contiguous().float()
+        wf = P["final_conv.weight"]
+        dcur, dwf, dbf = ops.conv_out_bwd(dlogits, sv.last, wf.detach().view(self.n_classes, -1).contiguous(), ws)
+        grads["final_conv.weight"], grads["final_conv.bias"] = dwf.view_as(wf), dbf
+        emit(["final_conv.weight", "final_conv.bias"])
+        dskips = [None] * L
+        for j in reversed(range(L)):
+            f = list(reversed(self.features))[j]
+            p = f"ups.{2 * j + 1}"
+            dskip, dup = self._block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
+            emit(_double_conv_names(p))
+            dskips[L - 1 - j] = dskip
+            xin = sv.up_in[j]
+            tname = f"ups.{2 * j}"
+            grads[tname + ".bias"] = ops.channel_sum(dup, ws)
+            grads[tname + ".weight"] = ops.convT_wgrad(xin, dup, ws)
+            dcur = ops.dense(xin.N, xin.H, xin.W, xin.C, dt, dev)
+            ops.convT_dgrad(dup, self.packed(tname + ".weight", P[tname + ".weight"], 3, dt), xin.C, dcur)
+            del dup
+            emit([tname + ".weight", tname + ".bias"])
+        dcur = self._block_bwd(P, sv, "bottleneck", dcur, grads, dt)
+        emit(_double_conv_names("bottleneck"))
+        for i in reversed(range(L)):
+            dy2 = ops.maxpool_bwd(dcur, sv.codes[i], dskips[i])
+            dskips[i] = None
+            dcur = self._block_bwd(P, sv, f"downs.{i}", dy2, grads, dt, need_dx=(i > 0))
+            emit(_double_conv_names(f"downs.{i}"))
+        return grads

@@ -1,0 +1,111 @@
+"""UNet with the reference's constructor, registration order and state_dict, computed by HIP kernels.
+
+Mirrors /root/reference/models/unet.py:5-67.  The nn.Conv2d / nn.BatchNorm2d / nn.ConvTranspose2d
+children are parameter containers only (same names, shapes, init order => same state_dict and, under
+the same torch.manual_seed, the same initial weights as the reference); forward runs
+unet_amd.engine.UNetEngine on the GPU.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import UNetEngine
+
+
+class DoubleConv(nn.Module):
+    """(convolution => [BN] => ReLU) * 2 -- parameter layout of models/unet.py:5-19."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1),
+            nn.BatchNorm2d(out_channels),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):
+        raise ops.UNetHipError("DoubleConv is executed by UNet.forward on the HIP engine; it has no standalone path")
+
+
+def resolve_dtype(module) -> int:
+    """bf16 under torch.autocast (the reference's `amp: true`), else fp32 (`amp: false`);
+    `module.compute_dtype` or UNET_AMD_DTYPE ('bf16' / 'fp32') override."""
+    forced = getattr(module, "compute_dtype", None) or os.environ.get("UNET_AMD_DTYPE")
+    if forced:
+        forced = str(forced).lower()
+        if forced in ("bf16", "bfloat16"):
+            return ops.BF16
+        if forced in ("fp32", "float32", "f32"):
+            return ops.F32
+        raise ops.UNetHipError(f"unknown compute dtype {forced!r}")
+    return ops.BF16 if torch.is_autocast_enabled() else ops.F32
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, dt, need_grad, x, *params):
+        names = module._param_names
+        P = dict(zip(names, params))
+        B = dict(module.named_buffers())
+        logits, sv = module._engine.forward(x, P, B, dt, module.training, need_grad)
+        ctx.module, ctx.sv, ctx.names = module, sv, names
+        ctx.P = P if need_grad else None
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        module, sv = ctx.module, ctx.sv
+        if sv is None:
+            raise ops.UNetHipError("backward through a forward that did not save activations")
+        hook = getattr(module, "_grad_hook", None)
+        grads = module._engine.backward(dlogits, ctx.P, sv, hook)
+        ctx.sv = None
+        out = []
+        for n in ctx.names:
+            p = ctx.P[n]
+            out.append(grads.get(n) if p.requires_grad else None)
+        return (None, None, None, None, *out)
+
+
+class UNet(nn.Module):
+    def __init__(self, in_channels=1, n_classes=3, features=[64, 128, 256, 512]):
+        super().__init__()
+        features = list(features)
+        self.ups = nn.ModuleList()
+        self.downs = nn.ModuleList()
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        cin = in_channels
+        for feature in features:
+            self.downs.append(DoubleConv(cin, feature))
+            cin = feature
+        for feature in reversed(features):
+            self.ups.append(nn.ConvTranspose2d(feature * 2, feature, kernel_size=2, stride=2))
+            self.ups.append(DoubleConv(feature * 2, feature))
+        self.bottleneck = DoubleConv(features[-1], features[-1] * 2)
+        self.final_conv = nn.Conv2d(features[0], n_classes, kernel_size=1)
+
+        for f in features:
+            if f % 8:
+                raise ValueError(f"unet_amd needs every feature width to be a multiple of 8 (got {features})")
+        if in_channels > 4:
+            raise ValueError("unet_amd's first-layer kernel serves in_channels <= 4")
+        if not 1 <= n_classes <= 8:
+            raise ValueError("unet_amd serves 1..8 classes")
+        self._engine = UNetEngine(features, in_channels, n_classes)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self.compute_dtype = None
+        self._grad_hook = None
+
+    def forward(self, x, current_epoch=None):
+        params = [p for _, p in self.named_parameters()]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
+
+
+def build_unet(**kwargs):
+    return UNet(**kwargs)

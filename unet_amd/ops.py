@@ -1,0 +1,429 @@
+"""Tensor-level wrappers over the C ABI (include/unet_hip.h).
+
+Every function takes torch CUDA(HIP) tensors, checks shapes on the host (a kernel fault can reset
+the whole GPU host) and enqueues the HIP kernel on torch's current stream.  torch is used for
+device memory and streams only.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ._lib import UNetHipError, check, lib
+
+F32, BF16 = 0, 1
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def torch_dtype(dt: int):
+    return _TORCH_DT[dt]
+
+
+def dt_of(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise UNetHipError(f"unsupported activation dtype {t.dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise UNetHipError("unet_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback)")
+
+
+@dataclass
+class Act:
+    """A channel slice [off, off+C) of a contiguous NHWC buffer [N,H,W,ld]."""
+    buf: torch.Tensor
+    off: int
+    C: int
+
+    @property
+    def N(self): return self.buf.shape[0]
+    @property
+    def H(self): return self.buf.shape[1]
+    @property
+    def W(self): return self.buf.shape[2]
+    @property
+    def ld(self): return self.buf.shape[3]
+    @property
+    def M(self): return self.buf.shape[0] * self.buf.shape[1] * self.buf.shape[2]
+    @property
+    def dt(self): return dt_of(self.buf)
+
+    def check(self):
+        b = self.buf
+        if b.dim() != 4 or not b.is_contiguous() or not b.is_cuda:
+            raise UNetHipError("activation buffers must be contiguous 4-D NHWC device tensors")
+        if self.off < 0 or self.off + self.C > b.shape[3]:
+            raise UNetHipError("channel slice outside the buffer")
+        return self
+
+
+def dense(N, H, W, C, dt, device) -> Act:
+    return Act(torch.empty((N, H, W, C), dtype=_TORCH_DT[dt], device=device), 0, C)
+
+
+class Workspace:
+    """Small fp64/fp32 scratch reused by stream-ordered kernels, plus the wgrad slab."""
+
+    def __init__(self, device):
+        self.device = device
+        self.acc = torch.empty(16384, dtype=torch.float64, device=device)
+        self.c1c2 = torch.empty(8192, dtype=torch.float32, device=device)
+        self.slab = None
+
+    def get_slab(self, nfloats):
+        if self.slab is None or self.slab.numel() < nfloats:
+            self.slab = None
+            self.slab = torch.empty(nfloats, dtype=torch.float32, device=self.device)
+        return self.slab
+
+
+# ----------------------------------------------------------------------------- packing
+
+def pack_weights(w: torch.Tensor, mode: int, dt: int) -> torch.Tensor:
+    """fp32 OIHW (modes 0,1) or (Cin,Cout,2,2) (modes 2,3) -> packed compute-dtype image."""
+    _need_cuda(w)
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    O, I = w.shape[0], w.shape[1]
+    nt = w.shape[2] * w.shape[3]
+    out = torch.empty(w.numel(), dtype=_TORCH_DT[dt], device=w.device)
+    check(lib().unet_pack_weights(dt, mode, _p(w), _p(out), O, I, nt, _stream()), "pack_weights")
+    return out
+
+
+# ----------------------------------------------------------------------------- convolutions
+
+def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act, kh: int, kw: int,
+             Cin: int, Cout: int, stats: bool = False, stride_h: int = 1, epi: int = 0,
+             pad_h: Optional[int] = None, pad_w: Optional[int] = None,
+             y2: Optional[Act] = None, csplit: int = 0):
+    """y = conv(x) (+bias).  Returns the BN partial-stat rows tensor when stats=True.
+    epi=1: 1x1 conv with Cout = 4*C and 2x2 pixel shuffle into y (ConvTranspose2d forward)."""
+    x.check(); y.check()
+    dt = x.dt
+    if y.dt != dt or wpacked.dtype != _TORCH_DT[dt]:
+        raise UNetHipError("conv: dtype mismatch between input, weights and output")
+    if x.C != Cin:
+        raise UNetHipError(f"conv: input slice has {x.C} channels, weights expect {Cin}")
+    if wpacked.numel() != kh * kw * Cin * Cout:
+        raise UNetHipError("conv: packed weight size mismatch")
+    ph = kh // 2 if pad_h is None else pad_h
+    pw = kw // 2 if pad_w is None else pad_w
+    Hout = (x.H + 2 * ph - kh) // stride_h + 1
+    Wout = x.W + 2 * pw - kw + 1
+    if epi == 1:
+        if (y.N, y.H, y.W) != (x.N, 2 * Hout, 2 * Wout) or y.C * 4 != Cout:
+            raise UNetHipError("convT: output buffer shape mismatch")
+    else:
+        ytot = y.C + (y2.C if y2 is not None else 0)
+        if (y.N, y.H, y.W) != (x.N, Hout, Wout) or ytot != Cout:
+            raise UNetHipError(f"conv: output buffer shape mismatch {(y.N, y.H, y.W, ytot)} vs {(x.N, Hout, Wout, Cout)}")
+        if y2 is not None:
+            y2.check()
+            if (y2.N, y2.H, y2.W) != (x.N, Hout, Wout) or csplit != y.C:
+                raise UNetHipError("conv: split output mismatch")
+    if bias is not None:
+        _need_cuda(bias)
+        nb = Cout // 4 if epi == 1 else Cout
+        if bias.numel() != nb or bias.dtype != torch.float32:
+            raise UNetHipError("conv: bias must be fp32 of length Cout")
+    rows = None
+    if stats:
+        nrows = lib().unet_conv_tiles(x.N, Hout, Wout)
+        rows = torch.empty((nrows, Cout, 2), dtype=torch.float32, device=x.buf.device)
+    check(lib().unet_conv_fwd(dt, kh, kw, stride_h, epi, _p(x.buf), _p(wpacked), _p(bias), _p(y.buf), _p(rows),
+                              x.N, x.H, x.W, Cin, x.ld, x.off, Hout, Wout, Cout, y.ld, y.off, ph, pw,
+                              _p(y2.buf) if y2 is not None else None, y2.ld if y2 is not None else 0,
+                              y2.off if y2 is not None else 0, csplit if y2 is not None else 0, _stream()), "conv_fwd")
+    return rows
+
+
+def conv_wgrad(dz: Act, x: Act, kh: int, kw: int, ws: Workspace, dw: Optional[torch.Tensor] = None,
+               stride_h: int = 1, pad_h: Optional[int] = None, pad_w: Optional[int] = None,
+               dw_taps: Optional[int] = None, dw_tap0: int = 0, accumulate: bool = False, reduce: bool = True):
+    """dW[o][i][tap] = sum_pixels dz[.,o] * x[. + tap, i].  Returns (dw, nsplit, slab)."""
+    dz.check(); x.check()
+    dt = x.dt
+    if dz.dt != dt:
+        raise UNetHipError("wgrad: dtype mismatch")
+    ph = kh // 2 if pad_h is None else pad_h
+    pw = kw // 2 if pad_w is None else pad_w
+    Cout, Cin = dz.C, x.C
+    if dz.N != x.N:
+        raise UNetHipError("wgrad: batch mismatch")
+    nt = kh * kw
+    dw_taps = nt if dw_taps is None else dw_taps
+    nsplit = lib().unet_conv_wgrad_splits(dt, dz.N, dz.H, dz.W, Cin, Cout)
+    slab = ws.get_slab(nsplit * nt * Cout * Cin)
+    if reduce and dw is None:
+        dw = torch.empty((Cout, Cin, dw_taps), dtype=torch.float32, device=x.buf.device)
+    if reduce and (dw.numel() != Cout * Cin * dw_taps or dw.dtype != torch.float32 or not dw.is_contiguous()):
+        raise UNetHipError("wgrad: gradient tensor shape mismatch")
+    check(lib().unet_conv_wgrad(dt, kh, kw, stride_h, _p(dz.buf), _p(x.buf), _p(slab), _p(dw) if reduce else None,
+                                1 if accumulate else 0, dw_taps, dw_tap0,
+                                x.N, x.H, x.W, Cin, x.ld, x.off, dz.H, dz.W, Cout, dz.ld, dz.off, ph, pw, _stream()),
+          "conv_wgrad")
+    return dw, nsplit, slab
+
+
+def convT_wgrad(xin: Act, dup: Act, ws: Workspace) -> torch.Tensor:
+    """Weight grad (Ci,Co,2,2) of ConvTranspose2d(k=2,s=2): xin [N,h,w,Ci], dup DENSE [N,2h,2w,Co]."""
+    if dup.off != 0 or dup.ld != dup.C:
+        raise UNetHipError("convT wgrad needs a dense output-gradient buffer")
+    Ci, Co = xin.C, dup.C
+    view = Act(dup.buf.view(dup.N, dup.H, dup.W // 2, 2 * Co), 0, 2 * Co)
+    _, nsplit, slab = conv_wgrad(xin, view, 2, 1, ws, stride_h=2, pad_h=0, pad_w=0, reduce=False)
+    dw = torch.empty((Ci, Co, 2, 2), dtype=torch.float32, device=xin.buf.device)
+    check(lib().unet_convT_wgrad_reduce(_p(slab), _p(dw), nsplit, Ci, Co, _stream()), "convT_wgrad_reduce")
+    return dw
+
+
+def convT_dgrad(dup: Act, wpacked3: torch.Tensor, Ci: int, out: Act):
+    """dx [N,h,w,Ci] of ConvTranspose2d(k=2,s=2) from the dense output gradient [N,2h,2w,Co]."""
+    if dup.off != 0 or dup.ld != dup.C:
+        raise UNetHipError("convT dgrad needs a dense output-gradient buffer")
+    Co = dup.C
+    view = Act(dup.buf.view(dup.N, dup.H, dup.W // 2, 2 * Co), 0, 2 * Co)
+    conv_fwd(view, wpacked3, None, out, 2, 1, 2 * Co, Ci, stride_h=2, pad_h=0, pad_w=0)
+
+
+def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], z: Act, kh: int, kw: int, stats=True):
+    """x fp32 [N,H,W,Cin] (Cin<=4), w fp32 OIHW -> z (dense) and BN partial rows."""
+    _need_cuda(x, w)
+    z.check()
+    N, H, W, Cin = x.shape
+    Cout = z.C
+    if x.dtype != torch.float32 or not x.is_contiguous() or z.off != 0 or z.ld != Cout or (z.N, z.H, z.W) != (N, H, W):
+        raise UNetHipError("first conv: bad input/output layout")
+    if tuple(w.shape) != (Cout, Cin, kh, kw) or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("first conv: bad weight tensor")
+    rows = None
+    if stats:
+        nrows = lib().unet_conv_first_rows(z.dt, N, H, W, Cout)
+        if nrows <= 0:
+            raise UNetHipError("first conv: unsupported Cout")
+        rows = torch.empty((nrows, Cout, 2), dtype=torch.float32, device=x.device)
+    check(lib().unet_conv_first_fwd(z.dt, kh, kw, _p(x), _p(w), _p(bias), _p(z.buf), _p(rows), N, H, W, Cin, Cout, _stream()),
+          "conv_first_fwd")
+    return rows
+
+
+def conv_first_wgrad(dz: Act, x: torch.Tensor, kh: int, kw: int, ws: Workspace) -> torch.Tensor:
+    dz.check()
+    N, H, W, Cin = x.shape
+    Cout = dz.C
+    if dz.off != 0 or dz.ld != Cout or (dz.N, dz.H, dz.W) != (N, H, W):
+        raise UNetHipError("first conv wgrad: bad gradient layout")
+    dw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
+    check(lib().unet_conv_first_wgrad(dz.dt, kh, kw, _p(dz.buf), _p(x), _p(dw), N, H, W, Cin, Cout, _p(ws.acc), _stream()),
+          "conv_first_wgrad")
+    return dw
+
+
+def conv_out_fwd(x: Act, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """final 1x1 conv -> fp32 NCHW logits."""
+    x.check()
+    K, C = w.shape[0], w.shape[1]
+    if C != x.C or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("final conv: bad weight tensor")
+    logits = torch.empty((x.N, K, x.H, x.W), dtype=torch.float32, device=x.buf.device)
+    check(lib().unet_conv_out_fwd(x.dt, _p(x.buf), x.ld, x.off, _p(w), _p(bias), _p(logits), x.M, x.H * x.W, C, K, _stream()),
+          "conv_out_fwd")
+    return logits
+
+
+def conv_out_bwd(dlogits: torch.Tensor, x: Act, w: torch.Tensor, ws: Workspace):
+    x.check()
+    K, C = w.shape[0], w.shape[1]
+    if dlogits.dtype != torch.float32 or not dlogits.is_contiguous() or tuple(dlogits.shape) != (x.N, K, x.H, x.W):
+        raise UNetHipError("final conv bwd: dlogits must be contiguous fp32 NCHW")
+    if K * C + K > ws.acc.numel():
+        raise UNetHipError("final conv bwd: workspace too small")
+    dx = dense(x.N, x.H, x.W, C, x.dt, x.buf.device)
+    dw = torch.empty((K, C, 1, 1), dtype=torch.float32, device=x.buf.device)
+    db = torch.empty((K,), dtype=torch.float32, device=x.buf.device)
+    check(lib().unet_conv_out_bwd(x.dt, _p(dlogits), _p(x.buf), x.ld, x.off, _p(w), _p(dx.buf), _p(dw), _p(db),
+                                  x.M, x.H * x.W, C, K, _p(ws.acc), _stream()), "conv_out_bwd")
+    return dx, dw, db
+
+
+# ----------------------------------------------------------------------------- BN / ReLU / pool
+
+@dataclass
+class BNState:
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: Optional[torch.Tensor] = None
+    invstd: Optional[torch.Tensor] = None
+
+
+def bn_finalize(rows: torch.Tensor, count: int, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                ws: Workspace) -> BNState:
+    C = rows.shape[1]
+    dev = rows.device
+    if 2 * C > ws.acc.numel():
+        raise UNetHipError("bn_finalize: workspace too small")
+    buf = torch.empty((4, C), dtype=torch.float32, device=dev)
+    st = BNState(buf[0], buf[1], buf[2], buf[3])
+    check(lib().unet_bn_finalize(_p(rows), rows.shape[0], C, count, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                 _p(nbt), float(momentum), float(eps), _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                 _p(ws.acc), _stream()), "bn_finalize")
+    return st
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps) -> BNState:
+    C = gamma.numel()
+    buf = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    check(lib().unet_bn_eval_coeffs(C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(buf[0]), _p(buf[1]),
+                                    _stream()), "bn_eval_coeffs")
+    return BNState(buf[0], buf[1])
+
+
+def affine_act(z: Act, y: Act, st: BNState, relu=True):
+    z.check(); y.check()
+    if z.C != y.C or z.M != y.M or z.dt != y.dt or st.scale.numel() != z.C:
+        raise UNetHipError("affine_act: shape mismatch")
+    check(lib().unet_affine_act(z.dt, 1 if relu else 0, _p(z.buf), z.ld, z.off, _p(y.buf), y.ld, y.off,
+                                _p(st.scale), _p(st.shift), z.M, z.C, _stream()), "affine_act")
+
+
+def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True, want_dbias=True):
+    """-> (dgamma, dbeta, dbias|None); dz is written."""
+    dy.check(); z.check(); dz.check()
+    C = z.C
+    if dy.C != C or dz.C != C or dy.M != z.M or dz.M != z.M or dy.dt != z.dt or dz.dt != z.dt:
+        raise UNetHipError("bn_relu_bwd: shape mismatch")
+    if 3 * C > ws.acc.numel() or 2 * C > ws.c1c2.numel():
+        raise UNetHipError("bn_relu_bwd: workspace too small")
+    g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
+    check(lib().unet_bn_relu_bwd(z.dt, 1 if relu else 0, _p(dy.buf), dy.ld, dy.off, _p(z.buf), z.ld, z.off,
+                                 _p(dz.buf), dz.ld, dz.off, _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                 _p(g[0]), _p(g[1]), _p(g[2]) if want_dbias else None, _p(ws.c1c2), _p(ws.acc),
+                                 z.M, C, _stream()), "bn_relu_bwd")
+    return g[0], g[1], (g[2] if want_dbias else None)
+
+
+def relu_bwd(dy: Act, y: Act, dz: Act):
+    dy.check(); y.check(); dz.check()
+    check(lib().unet_relu_bwd(y.dt, _p(dy.buf), dy.ld, dy.off, _p(y.buf), y.ld, y.off, _p(dz.buf), dz.ld, dz.off,
+                              y.M, y.C, _stream()), "relu_bwd")
+
+
+def channel_sum(x: Act, ws: Workspace, out: Optional[torch.Tensor] = None, accumulate=False) -> torch.Tensor:
+    x.check()
+    if out is None:
+        out = torch.empty((x.C,), dtype=torch.float32, device=x.buf.device)
+    check(lib().unet_channel_sum(x.dt, _p(x.buf), x.ld, x.off, x.M, x.C, _p(out), 1 if accumulate else 0, _p(ws.acc), _stream()),
+          "channel_sum")
+    return out
+
+
+def maxpool_fwd(x: Act):
+    """-> (pooled dense Act, uint8 code tensor [N,H/2,W/2,C])."""
+    x.check()
+    if x.H % 2 or x.W % 2:
+        raise UNetHipError(f"maxpool: H and W must be even, got {x.H}x{x.W}")
+    y = dense(x.N, x.H // 2, x.W // 2, x.C, x.dt, x.buf.device)
+    code = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.uint8, device=x.buf.device)
+    check(lib().unet_maxpool2x2_fwd(x.dt, _p(x.buf), x.ld, x.off, _p(y.buf), _p(code), x.N, x.H, x.W, x.C, _stream()), "maxpool_fwd")
+    return y, code
+
+
+def maxpool_bwd(dy: Act, code: torch.Tensor, dskip: Optional[Act]) -> Act:
+    """dx[N,H,W,C] = unpool(dy) (+ dskip)."""
+    dy.check()
+    if dy.off != 0 or dy.ld != dy.C:
+        raise UNetHipError("maxpool_bwd: pooled gradient must be dense")
+    N, Ho, Wo, C = dy.N, dy.H, dy.W, dy.C
+    if tuple(code.shape) != (N, Ho, Wo, C):
+        raise UNetHipError("maxpool_bwd: code shape mismatch")
+    if dskip is not None:
+        dskip.check()
+        if (dskip.N, dskip.H, dskip.W, dskip.C) != (N, 2 * Ho, 2 * Wo, C):
+            raise UNetHipError("maxpool_bwd: skip gradient shape mismatch")
+    dx = dense(N, 2 * Ho, 2 * Wo, C, dy.dt, dy.buf.device)
+    check(lib().unet_maxpool2x2_bwd(dy.dt, _p(dy.buf), _p(code), _p(dskip.buf) if dskip is not None else None,
+                                    dskip.ld if dskip is not None else 0, dskip.off if dskip is not None else 0,
+                                    _p(dx.buf), N, 2 * Ho, 2 * Wo, C, _stream()), "maxpool_bwd")
+    return dx
+
+
+def pool_indices_int64(code: torch.Tensor, W: int) -> torch.Tensor:
+    """2-bit code -> torch's int64 flat index (h*W + w) into the input plane, NCHW order."""
+    N, Ho, Wo, C = code.shape
+    c = code.to(torch.int64)
+    ho = torch.arange(Ho, device=code.device).view(1, Ho, 1, 1)
+    wo = torch.arange(Wo, device=code.device).view(1, 1, Wo, 1)
+    idx = (2 * ho + (c >> 1)) * W + 2 * wo + (c & 1)
+    return idx.permute(0, 3, 1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------- loss & friends
+
+def dice_ce_fwd(logits: torch.Tensor, target: torch.Tensor, ce_w, dice_w, ignore_index, ce_only=False, eps=1e-6):
+    _need_cuda(logits, target)
+    if logits.dim() != 4 or logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise UNetHipError("dice_ce: logits must be contiguous fp32 NCHW")
+    N, C, H, W = logits.shape
+    if target.dtype != torch.int64 or tuple(target.shape) != (N, H, W) or not target.is_contiguous():
+        raise UNetHipError("dice_ce: target must be contiguous int64 [N,H,W]")
+    acc = torch.empty(N * C * 3 + 3, dtype=torch.float64, device=logits.device)
+    out4 = torch.empty(4, dtype=torch.float32, device=logits.device)
+    check(lib().unet_dice_ce_fwd(_p(logits), _p(target), N, C, H * W, float(ce_w), float(dice_w), int(ignore_index),
+                                 1 if ce_only else 0, float(eps), _p(acc), _p(out4), _stream()), "dice_ce_fwd")
+    return out4, acc
+
+
+def dice_ce_bwd(logits, target, acc, grad_out, ce_w, dice_w, ignore_index, ce_only=False, eps=1e-6):
+    N, C, H, W = logits.shape
+    dl = torch.empty_like(logits)
+    if grad_out is not None:
+        grad_out = grad_out.reshape(1).float().contiguous()
+    check(lib().unet_dice_ce_bwd(_p(logits), _p(target), N, C, H * W, float(ce_w), float(dice_w), int(ignore_index),
+                                 1 if ce_only else 0, float(eps), _p(acc), _p(grad_out), _p(dl), _stream()), "dice_ce_bwd")
+    return dl
+
+
+def argmax(logits: torch.Tensor) -> torch.Tensor:
+    _need_cuda(logits)
+    if logits.dim() != 4 or logits.dtype != torch.float32 or not logits.is_contiguous():
+        raise UNetHipError("argmax: logits must be contiguous fp32 NCHW")
+    N, C, H, W = logits.shape
+    out = torch.empty((N, H, W), dtype=torch.int64, device=logits.device)
+    check(lib().unet_argmax(_p(logits), _p(out), N, C, H * W, _stream()), "argmax")
+    return out
+
+
+def ensemble_fuse(l1: torch.Tensor, l2: torch.Tensor, thresh: float = 0.6) -> torch.Tensor:
+    _need_cuda(l1, l2)
+    if l1.shape != l2.shape or l1.dtype != torch.float32 or l2.dtype != torch.float32:
+        raise UNetHipError("ensemble_fuse: two fp32 NCHW logits tensors of equal shape expected")
+    l1, l2 = l1.contiguous(), l2.contiguous()
+    N, C, H, W = l1.shape
+    out = torch.empty((N, H, W), dtype=torch.int64, device=l1.device)
+    check(lib().unet_ensemble_fuse(_p(l1), _p(l2), _p(out), N, C, H * W, float(thresh), _stream()), "ensemble_fuse")
+    return out
+
+
+def seg_counts(pred: torch.Tensor, target: torch.Tensor, K: int) -> torch.Tensor:
+    _need_cuda(pred, target)
+    if pred.dtype != torch.int64 or target.dtype != torch.int64 or pred.shape != target.shape:
+        raise UNetHipError("seg_counts: int64 tensors of equal shape expected")
+    pred, target = pred.contiguous(), target.contiguous()
+    counts = torch.empty(66, dtype=torch.int64, device=pred.device)
+    check(lib().unet_seg_counts(_p(pred), _p(target), pred.numel(), K, _p(counts), _stream()), "seg_counts")
+    return counts

@@ -1,0 +1,118 @@
+"""Batch-sharded data parallelism over RCCL (one process per GPU), replacing the reference's
+DistributedDataParallel wrap (/root/reference/train.py:139-144).
+
+  * parameters and buffers are broadcast from rank 0 at wrap time; BN buffers again before every
+    training forward (DDP's broadcast_buffers=True default); BatchNorm statistics stay per rank
+    (the reference leaves SyncBatchNorm commented out, train.py:142);
+  * gradients are averaged with bucketed all-reduces launched from INSIDE the explicit backward
+    schedule: the engine hands each layer's gradients over as soon as their kernels are enqueued
+    (backward-arrival order: final_conv, ups.7 .. ups.0, bottleneck, downs.3 .. downs.0), a bucket is
+    all-reduced asynchronously on the process group's stream as soon as it is full, and
+    finish_grad_sync() (called by step_batch before clipping) waits and scatters the averages into
+    p.grad.  xGMI is point-to-point, so buckets are large (default 32 MiB: 4 all-reduces per step).
+"""
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class BucketReducer:
+    """Average named gradient tensors across the process group in arrival-order buckets."""
+
+    def __init__(self, process_group=None, bucket_bytes: int = 32 << 20, comm_dtype: Optional[torch.dtype] = None):
+        self.pg = process_group
+        self.bucket_bytes = int(bucket_bytes)
+        self.comm_dtype = comm_dtype
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._pending: List = []          # (names, shapes, flat, work)
+        self._cur_names: List[str] = []
+        self._cur: List[torch.Tensor] = []
+        self._cur_bytes = 0
+        self.buckets_launched = 0
+
+    def add(self, names: List[str], tensors: List[torch.Tensor]):
+        for n, t in zip(names, tensors):
+            if t is None:
+                continue
+            self._cur_names.append(n)
+            self._cur.append(t)
+            self._cur_bytes += t.numel() * t.element_size()
+        if self._cur_bytes >= self.bucket_bytes:
+            self._launch()
+
+    def _launch(self):
+        if not self._cur:
+            return
+        dtype = self.comm_dtype or self._cur[0].dtype
+        flat = torch.cat([t.reshape(-1).to(dtype) for t in self._cur])
+        work = None
+        if self.world > 1:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._pending.append((self._cur_names, [t.shape for t in self._cur], flat, work))
+        self._cur_names, self._cur, self._cur_bytes = [], [], 0
+        self.buckets_launched += 1
+
+    def finish(self) -> Dict[str, torch.Tensor]:
+        """Wait for every bucket; returns {name: averaged gradient view}."""
+        self._launch()
+        out: Dict[str, torch.Tensor] = {}
+        for names, shapes, flat, work in self._pending:
+            if work is not None:
+                work.wait()
+            if self.world > 1:
+                flat.div_(self.world)
+            off = 0
+            for n, s in zip(names, shapes):
+                k = 1
+                for d in s:
+                    k *= d
+                out[n] = flat[off:off + k].view(s)
+                off += k
+        self._pending = []
+        return out
+
+
+class DataParallel(nn.Module):
+    """DDP-shaped wrapper (`.module`, same forward) for unet_amd models."""
+
+    def __init__(self, module: nn.Module, device_ids=None, output_device=None, process_group=None,
+                 bucket_cap_mb: float = 32, broadcast_buffers: bool = True, comm_dtype: Optional[torch.dtype] = None):
+        super().__init__()
+        self.module = module
+        self.pg = process_group
+        self.broadcast_buffers = broadcast_buffers
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.reducer = BucketReducer(process_group, int(bucket_cap_mb * (1 << 20)), comm_dtype)
+        self._params = dict(module.named_parameters())
+        module._grad_hook = self.reducer.add
+        if self.world > 1:
+            self._broadcast([p.data for p in module.parameters()])
+            self._broadcast([b.data for b in module.buffers()])
+
+    def _broadcast(self, tensors: List[torch.Tensor]):
+        """rank 0 -> all, coalesced per dtype into one flat message."""
+        by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+        for t in tensors:
+            by_dtype.setdefault(t.dtype, []).append(t)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+    def forward(self, *args, **kwargs):
+        if self.world > 1 and self.broadcast_buffers and self.module.training:
+            self._broadcast([b.data for b in self.module.buffers()])
+        return self.module(*args, **kwargs)
+
+    def finish_grad_sync(self):
+        """Called after loss.backward(): p.grad <- average over ranks."""
+        avg = self.reducer.finish()
+        for n, g in avg.items():
+            p = self._params[n]
+            if p.grad is not None:
+                p.grad.copy_(g)

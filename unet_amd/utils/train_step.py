@@ -1,0 +1,74 @@
+"""step_batch with the reference's signature, return value and side effects
+(/root/reference/utils/train_step.py:7-79):
+
+    zero_grad -> (autocast) forward -> loss -> scaled backward -> unscale + clip -> optimizer step
+    -> trainer._global_step += 1 -> info{'main_loss','lr'} -> on_batch_end callbacks
+
+Differences: autocast selects the bf16 HIP kernels (the reference's fp16 autocast has no bf16 path);
+the one host sync that fetches `main_loss` also carries the loss kernel's illegal-label counter, so a
+label the reference would have raised on still raises here.
+"""
+from contextlib import nullcontext
+from typing import Any, Dict, Tuple
+
+import torch
+
+
+def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int = 0) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
+    trainer.optimizer.zero_grad(set_to_none=True)
+
+    amp_on = getattr(trainer, "amp", False)
+    amp_ctx = torch.amp.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=True) if amp_on else nullcontext()
+    info: Dict[str, Any] = {}
+
+    with amp_ctx:
+        try:
+            outputs = trainer.model(x)
+        except TypeError:
+            outputs = trainer.model(x, current_epoch=getattr(trainer, "current_epoch", -1))
+        if isinstance(outputs, dict):
+            logits = outputs.get("logits", outputs.get("out", None))
+        elif isinstance(outputs, tuple):
+            logits = outputs[0]
+        else:
+            logits = outputs
+        if batch_idx == 0:
+            trainer.logger.debug(f"Step | Logits Shape: {logits.shape}")
+        if y.ndim == 4:
+            y = y.squeeze(1)
+            if batch_idx == 0:
+                trainer.logger.debug(f"Step | Y Squeezed: {y.shape}")
+        main_loss = trainer.loss_fn(logits, y)
+
+    scaler.scale(main_loss).backward()
+    sync = getattr(trainer.model, "finish_grad_sync", None)
+    if sync is not None:          # data-parallel wrapper: wait for the bucketed all-reduces
+        sync()
+
+    if trainer.grad_clip > 0:
+        scaler.unscale_(trainer.optimizer)
+        torch.nn.utils.clip_grad_norm_(trainer.model.parameters(), trainer.grad_clip)
+
+    scaler.step(trainer.optimizer)
+    scaler.update()
+
+    step_idx = int(getattr(trainer, "_global_step", 0)) + 1
+    setattr(trainer, "_global_step", step_idx)
+
+    status = getattr(main_loss, "_unet_status", None)
+    if status is not None:
+        vals = status.tolist()                      # the step's host sync
+        if vals[3] > 0:
+            raise RuntimeError("Class values must be smaller than num_classes.")
+        info["main_loss"] = vals[0]
+    else:
+        info["main_loss"] = main_loss.item()
+    info["lr"] = float(trainer.optimizer.param_groups[0]["lr"])
+
+    for cb in trainer.cbs:
+        if hasattr(cb, "on_batch_end"):
+            try:
+                cb.on_batch_end(trainer, step_idx, info)
+            except Exception:
+                pass
+    return main_loss, logits, info
