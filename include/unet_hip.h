@@ -40,8 +40,10 @@ int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                   int N, int Hin, int Win, int Cin, int ldx, int xoff,
                   int Hout, int Wout, int Cout, int ldy, int yoff,
                   int pad_h, int pad_w,
-                  void* y2, int ldy2, int yoff2, int csplit, void* stream);
-/* csplit > 0: output channels >= csplit are written to y2 (channel co - csplit) instead of y; the
+                  void* y2, int ldy2, int yoff2, int csplit, int flags, void* stream);
+/* flags bit 0: y += conv(x) (the RepUNet branch dgrads sum into one input gradient); bit 1: ReLU
+ * on the stored result (deployed RepUNet: conv + bias + ReLU, models/reparm_unet.py:162-167).
+ * csplit > 0: output channels >= csplit are written to y2 (channel co - csplit) instead of y; the
  * dgrad of the first decoder conv uses it to hand the skip half and the upsampled half of the
  * concat gradient to two dense buffers (torch.cat backward, models/unet.py:59). */
 
@@ -127,6 +129,30 @@ int unet_ensemble_fuse(const float* logits1, const float* logits2, long long* ou
 /* confusion counts for calculate_segmentation_metrics -- utils/eval_utils.py:16-40; counts[66] */
 int unet_seg_counts(const long long* pred, const long long* target, long long total, int K,
                     unsigned long long* counts, void* stream);
+
+/* ---- RepUNet training path: GroupNorm + multi-branch sum -- models/reparm_unet.py:17-25,67-72,114-122
+ * stat_rows: the conv epilogue's rows, grouped per image ([N][rows_per_image][C][2]). */
+int unet_gn_finalize(const float* stat_rows, int N, int rows_per_image, int C, int groups, long long HW,
+                     const float* gamma, const float* beta, float eps,
+                     float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* y = act(sum_b z_b*scale_b + shift_b); z/scale/shift are HOST arrays of nb device pointers;
+ * coef_nstride = C (per-sample coefficients, GroupNorm) or 0 (per-channel, BatchNorm variant) */
+int unet_branch_sum_act(int dtype, int relu, int nb, const void* const* z, const float* const* scale, const float* const* shift,
+                        int coef_nstride, void* y, int ldy, int yoff, int N, long long HW, int C, void* stream);
+/* GroupNorm backward of one branch; u = ReLU-masked upstream gradient.  acc_ws: N*C*2+C*2 doubles,
+ * coef_ws: 3*N*C floats. */
+int unet_gn_bwd(int dtype, const void* u, const void* z, void* dz, int N, long long HW, int C, int groups,
+                const float* gamma, const float* mean, const float* invstd,
+                float* dgamma, float* dbeta, double* acc_ws, float* coef_ws, void* stream);
+
+/* ---- RepUNet fold (switch_to_deploy) -- models/reparm_unet.py:28-37,74-82,124-135; bit-exact fp32 */
+int unet_fold_asymm(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,
+                    const float* sq_w, const float* sq_b, const float* sq_rm, const float* sq_rv,
+                    const float* ve_w, const float* ve_b, const float* ve_rm, const float* ve_rv,
+                    const float* ho_w, const float* ho_b, const float* ho_rm, const float* ho_rv,
+                    float eps, float* out_w, float* out_b, void* stream);
+int unet_fold_embed_add(int K, int k, int O, int I, float* target_w, const float* src_w, float* target_b,
+                        const float* src_b, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,6 +27,39 @@ BN_MOMENTUM = 0.1          # nn.BatchNorm2d default, unet.py:11,14
 REP_BN_MOMENTUM = 0.01     # commented-out BatchNorm variant, reparm_unet.py:14-15
 
 
+class _RoundBoth(torch.autograd.Function):
+    """bf16 storage emulation: the value is rounded going forward and its gradient going backward,
+    the two points where the HIP path stores a bf16 activation / activation gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 weight image of an fp32 master weight (gradient passes straight through)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _ra(x, emu):
+    return _RoundBoth.apply(x) if emu else x
+
+
+def _rw(w, emu):
+    return _RoundFwd.apply(w) if emu else w
+
+
 def batchnorm(x, st: State, prefix: str, train: bool, momentum: float, new_buffers: Optional[State]):
     """nn.BatchNorm2d semantics: biased var normalises, unbiased var feeds running_var,
     running = (1-m)*running + m*stat, num_batches_tracked += 1 (train only)."""
@@ -47,12 +80,14 @@ def batchnorm(x, st: State, prefix: str, train: bool, momentum: float, new_buffe
     return y
 
 
-def double_conv(x, st: State, p: str, train: bool, nb: Optional[State]):
-    """unet.py:9-16: conv3x3(pad 1, bias) -> BN -> ReLU, twice; params at indices 0,1,3,4."""
-    x = F.conv2d(x, st[p + ".double_conv.0.weight"], st[p + ".double_conv.0.bias"], padding=1)
-    x = F.relu(batchnorm(x, st, p + ".double_conv.1", train, BN_MOMENTUM, nb))
-    x = F.conv2d(x, st[p + ".double_conv.3.weight"], st[p + ".double_conv.3.bias"], padding=1)
-    x = F.relu(batchnorm(x, st, p + ".double_conv.4", train, BN_MOMENTUM, nb))
+def double_conv(x, st: State, p: str, train: bool, nb: Optional[State], emu: bool = False, first: bool = False):
+    """unet.py:9-16: conv3x3(pad 1, bias) -> BN -> ReLU, twice; params at indices 0,1,3,4.
+    emu=True rounds to bf16 wherever the HIP bf16 path stores a tensor (conv output, BN+ReLU output,
+    packed weights; the Cin<=4 first conv keeps fp32 weights) so the bf16 kernels can be checked tightly."""
+    x = F.conv2d(x, _rw(st[p + ".double_conv.0.weight"], emu and not first), st[p + ".double_conv.0.bias"], padding=1)
+    x = _ra(F.relu(batchnorm(_ra(x, emu), st, p + ".double_conv.1", train, BN_MOMENTUM, nb)), emu)
+    x = F.conv2d(x, _rw(st[p + ".double_conv.3.weight"], emu), st[p + ".double_conv.3.bias"], padding=1)
+    x = _ra(F.relu(batchnorm(_ra(x, emu), st, p + ".double_conv.4", train, BN_MOMENTUM, nb)), emu)
     return x
 
 
@@ -64,7 +99,7 @@ def _levels(st: State) -> int:
     return n
 
 
-def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None):
+def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: bool = False):
     """Encoder/decoder wiring shared by UNet.forward (unet.py:41-62) and
     ReparamUNet.forward (reparm_unet.py:194-215): skip FIRST in the concat."""
     skips = []
@@ -77,7 +112,7 @@ def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None):
     x = block(x, "bottleneck")                                              # unet.py:49
     skips = skips[::-1]
     for j in range(n_levels):
-        x = F.conv_transpose2d(x, st[f"ups.{2*j}.weight"], st[f"ups.{2*j}.bias"], stride=2)  # unet.py:53
+        x = _ra(F.conv_transpose2d(x, _rw(st[f"ups.{2*j}.weight"], emu), st[f"ups.{2*j}.bias"], stride=2), emu)  # unet.py:53
         s = skips[j]
         if x.shape != s.shape:                                              # unet.py:56-57
             x = F.interpolate(x, size=s.shape[2:], mode="bilinear", align_corners=True)
@@ -86,9 +121,11 @@ def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None):
     return F.conv2d(x, st["final_conv.weight"], st["final_conv.bias"])      # unet.py:62
 
 
-def unet_forward(x, st: State, train: bool = True, new_buffers: Optional[State] = None, taps=None):
+def unet_forward(x, st: State, train: bool = True, new_buffers: Optional[State] = None, taps=None,
+                 emulate_bf16: bool = False):
     n = _levels(st)
-    return _wire(x, st, lambda t, p: double_conv(t, st, p, train, new_buffers), n, taps)
+    return _wire(x, st, lambda t, p: double_conv(t, st, p, train, new_buffers, emulate_bf16, first=(p == "downs.0" and t is x)),
+                 n, taps, emulate_bf16)
 
 
 # ---------------------------------------------------------------- RepUNet --------------

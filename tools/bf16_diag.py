@@ -15,7 +15,8 @@ for feats, n, h in (([8, 16], 2, 32), ([16, 32], 4, 64), ([16, 32, 64], 4, 128),
     x = torch.rand(n, 1, h, h, generator=g); y = (torch.rand(n, h, h, generator=g) > 0.95).long()
     names = [k for k in st if "running_" not in k and "num_batches" not in k]
     for k in names: st[k].requires_grad_(True)
-    rl = unet_ref.unet_forward(x, st, True, {})
+    emu = len(sys.argv) > 1
+    rl = unet_ref.unet_forward(x, st, True, {}, emulate_bf16=emu)
     loss_ref.ce_dice(rl, y, 1, 1, 255).backward()
     m = m.to(dev).train()
     for mode in ("fp32", "bf16"):

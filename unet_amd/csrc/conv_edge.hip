@@ -28,13 +28,15 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     float s1[EPV], s2[EPV], b[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { s1[e] = s2[e] = 0.f; b[e] = (bias != nullptr && active) ? bias[cg * EPV + e] : 0.f; }
-    const long long M = (long long)N * H * W;
+    // grid (gx, N): a workgroup stays inside image blockIdx.y, so its statistics row belongs to one
+    // sample (GroupNorm needs per-sample statistics); rows are ordered [n][bx]
+    const long long HW = (long long)H * W;
     if (active) {
-        for (long long p = (long long)blockIdx.x * PL + pl; p < M; p += (long long)gridDim.x * PL) {
-            const int wq = (int)(p % W);
-            const long long r = p / W;
-            const int hq = (int)(r % H);
-            const long long nb = (r / H) * H;             // n*H
+        for (long long q = (long long)blockIdx.x * PL + pl; q < HW; q += (long long)gridDim.x * PL) {
+            const long long p = (long long)blockIdx.y * HW + q;
+            const int wq = (int)(q % W);
+            const int hq = (int)(q / W);
+            const long long nb = (long long)blockIdx.y * H;             // n*H
             float acc[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) acc[e] = b[e];
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
         for (int i = threadIdx.x; i < Cout * 2; i += 256) {
             float s = 0.f;
             for (int p = 0; p < PL; ++p) s += red[p * Cout * 2 + i];
-            stats[(size_t)blockIdx.x * Cout * 2 + i] = s;
+            stats[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Cout * 2 + i] = s;
         }
     }
 }
@@ -316,12 +318,21 @@ static inline int grid_for(long long M, int PL) {
     return (int)g;
 }
 
-extern "C" int unet_conv_first_rows(int dtype, int N, int H, int W, int Cout) {
+static int first_gx(int dtype, int N, int H, int W, int Cout) {
     const int epv = dtype == UNET_BF16 ? 8 : 4;
-    if (Cout <= 0 || Cout % epv) return -1;
+    if (Cout <= 0 || Cout % epv || N <= 0) return -1;
     const int G = Cout / epv;
     if (G > 256) return -1;
-    return grid_for((long long)N * H * W, 256 / G);
+    int cap = MAX_GRID / N; if (cap < 1) cap = 1;
+    long long g = ((long long)H * W + 256 / G - 1) / (256 / G);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+// rows of per-image statistics the first conv writes: N * (rows per image), ordered [n][bx]
+extern "C" int unet_conv_first_rows(int dtype, int N, int H, int W, int Cout) {
+    const int gx = first_gx(dtype, N, H, W, Cout);
+    return gx < 0 ? -1 : gx * N;
 }
 
 extern "C" int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, const float* w, const float* bias, void* z, float* stats,
@@ -337,7 +348,8 @@ extern "C" int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, co
     if (lds < red) lds = red;
     UNET_CHECK(lds <= 65536, "first-conv weights do not fit LDS");
     hipStream_t s = (hipStream_t)stream;
-#define LF(T, A, B) hipLaunchKernelGGL((conv_first_fwd_kernel<T, A, B>), dim3(rows), dim3(256), lds, s, x, w, bias, (T*)z, stats, N, H, W, Cin, Cout)
+    const int gx = rows / N;
+#define LF(T, A, B) hipLaunchKernelGGL((conv_first_fwd_kernel<T, A, B>), dim3(gx, N), dim3(256), lds, s, x, w, bias, (T*)z, stats, N, H, W, Cin, Cout)
 #define LFD(A, B) do { if (dtype == UNET_BF16) LF(__bf16, A, B); else LF(float, A, B); } while (0)
     if (kh == 3 && kw == 3) LFD(3, 3);
     else if (kh == 5 && kw == 5) LFD(5, 5);

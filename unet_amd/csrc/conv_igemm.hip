@@ -27,6 +27,7 @@ struct ConvArgs {
     // optional second destination: output channels >= csplit go to y2 at channel (co - csplit)
     void* y2;
     int ldy2, yoff2, csplit;
+    int flags;      // bit 0: y += conv (accumulate into the existing output), bit 1: ReLU on the result
 };
 
 template <typename T, int KH, int KW, int SH, int TG, int EPI>
@@ -199,6 +200,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                     T* dst = yout + idx;
                     if (EPI == 0 && a.csplit > 0 && cq >= a.csplit)
                         dst = (T*)a.y2 + (((size_t)n * a.Hout + ho) * a.Wout + wo) * a.ldy2 + a.yoff2 + (cq - a.csplit);
+                    if (a.flags & 1) {
+                        if (sizeof(T) == 2) {
+                            const uint2 old = *(const uint2*)dst;
+                            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        } else {
+                            const float4 old = *(const float4*)dst;
+                            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                        }
+                    }
+                    if (a.flags & 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
                     if (sizeof(T) == 2) {
                         uint2 pk;
                         pk.x = Vec16<__bf16>::pk(v[0], v[1]);
@@ -276,7 +291,7 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                              int N, int Hin, int Win, int Cin, int ldx, int xoff,
                              int Hout, int Wout, int Cout, int ldy, int yoff,
                              int pad_h, int pad_w,
-                             void* y2, int ldy2, int yoff2, int csplit, void* stream) {
+                             void* y2, int ldy2, int yoff2, int csplit, int flags, void* stream) {
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
     if (csplit > 0) UNET_CHECK(y2 != nullptr && csplit % 8 == 0 && ldy2 % 8 == 0 && yoff2 % 8 == 0 && epi == 0 && csplit < Cout,
                                "bad split-output arguments");
@@ -296,7 +311,7 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.ldy = ldy; a.yoff = yoff;
     a.pad_h = pad_h; a.pad_w = pad_w;
     a.tiles_h = (Hout + 7) / 8; a.tiles_w = (Wout + 31) / 32;
-    a.y2 = y2; a.ldy2 = ldy2; a.yoff2 = yoff2; a.csplit = csplit;
+    a.y2 = y2; a.ldy2 = ldy2; a.yoff2 = yoff2; a.csplit = csplit; a.flags = flags;
     hipStream_t s = (hipStream_t)stream;
     return dtype == UNET_BF16 ? dispatch_conv<__bf16>(kh, kw, stride_h, epi, a, s)
                               : dispatch_conv<float>(kh, kw, stride_h, epi, a, s);

@@ -1,0 +1,287 @@
+// RepUNet training-path kernels (gfx950, bandwidth-bound): GroupNorm statistics from the conv
+// epilogue rows, the multi-branch "sum of normalised convs + ReLU", and GroupNorm backward.
+//
+// Reference semantics: getBN -> nn.GroupNorm(min(8,C), C, eps=1e-5) (/root/reference/models/reparm_unet.py:17-25),
+// AsymmConvBlock.forward = GN(conv_kx1) + GN(conv_1xk) + GN(conv_kxk) (:67-72),
+// MultiConvBlock.forward = sum over kernel sizes (:114-122), then ReLU (ReparamDoubleConv :162-167).
+//
+// GroupNorm is per (sample, group): kernels here run on a grid (gx, N) so a workgroup stays inside
+// one image and its per-(n,c) coefficients live in registers.
+#include "common.h"
+
+#define MAX_BRANCH 8
+
+// ---------------------------------------------------------------------------------------------
+// rows [N*rpi][C][2] (per-tile sum / sumsq, tiles never cross images) -> per-(n,c) scale/shift and
+// per-(n,g) mean/invstd.  One workgroup per image.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ rows, int rpi, int C, int groups, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    extern __shared__ double sm_d[];          // [C][2] then [groups][2]
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < rpi; ++r) {
+            const float2 v = *(const float2*)(rows + (((size_t)n * rpi + r) * C + c) * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
+        }
+        sm_d[c * 2] = s1; sm_d[c * 2 + 1] = s2;
+    }
+    __syncthreads();
+    const int cg = C / groups;
+    double* gs = sm_d + 2 * C;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += sm_d[c * 2]; s2 += sm_d[c * 2 + 1]; }
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        if (var < 0.0) var = 0.0;
+        gs[g * 2] = m;
+        gs[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+        mean_out[n * groups + g] = (float)m;
+        invstd_out[n * groups + g] = (float)gs[g * 2 + 1];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cg;
+        const float sc = gamma[c] * (float)gs[g * 2 + 1];
+        scale[(size_t)n * C + c] = sc;
+        shift[(size_t)n * C + c] = beta[c] - (float)gs[g * 2] * sc;
+    }
+}
+
+struct BranchArgs {
+    const void* z[MAX_BRANCH];
+    const float* scale[MAX_BRANCH];
+    const float* shift[MAX_BRANCH];
+    int nb;
+    int coef_nstride;      // C for per-sample coefficients (GroupNorm), 0 for per-channel (BatchNorm)
+};
+
+// y[n,p,c] = act( sum_b z_b[n,p,c]*scale_b[n][c] + shift_b[n][c] ); branches dense [N,HW,C]
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void branch_sum_act_kernel(BranchArgs a, T* __restrict__ y, int ldy, int yoff, long long HW, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    if (pl >= PL) return;
+    const int n = blockIdx.y;
+    float sc[MAX_BRANCH][EPV], sh[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) sh[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MAX_BRANCH; ++b) {
+        if (b < a.nb) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                sc[b][e] = a.scale[b][(size_t)n * a.coef_nstride + cg * EPV + e];
+                sh[e] += a.shift[b][(size_t)n * a.coef_nstride + cg * EPV + e];
+            }
+        }
+    }
+    for (long long p = (long long)blockIdx.x * PL + pl; p < HW; p += (long long)gridDim.x * PL) {
+        const long long pix = (long long)n * HW + p;
+        float o[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) o[e] = sh[e];
+#pragma unroll
+        for (int b = 0; b < MAX_BRANCH; ++b) {
+            if (b < a.nb) {
+                float f[EPV];
+                Vec16<T>::unpack(*(const uint4*)((const T*)a.z[b] + pix * C + cg * EPV), f);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) o[e] = fmaf(f[e], sc[b][e], o[e]);
+            }
+        }
+        if (RELU) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        *(uint4*)(y + pix * ldy + yoff + cg * EPV) = Vec16<T>::pack(o);
+    }
+}
+
+// per-(n,c): S1 = sum_p u, S2 = sum_p u*v   (u = masked upstream gradient, v = branch conv output)
+template <typename T>
+__global__ __launch_bounds__(256) void pair_reduce_kernel(const T* __restrict__ u, const T* __restrict__ v, long long HW, int C,
+                                                          double* __restrict__ acc /* [N][C][2] */) {
+    constexpr int EPV = TT<T>::EPV;
+    extern __shared__ float sm_f[];
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    const int n = blockIdx.y;
+    float p1[EPV], p2[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) p1[e] = p2[e] = 0.f;
+    if (active) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < HW; p += (long long)gridDim.x * PL) {
+            const long long pix = (long long)n * HW + p;
+            float fu[EPV], fv[EPV];
+            Vec16<T>::unpack(*(const uint4*)(u + pix * C + cg * EPV), fu);
+            Vec16<T>::unpack(*(const uint4*)(v + pix * C + cg * EPV), fv);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { p1[e] += fu[e]; p2[e] = fmaf(fu[e], fv[e], p2[e]); }
+        }
+        // LDS [pl][cg][2*EPV]
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            sm_f[(pl * G + cg) * 2 * EPV + e] = p1[e];
+            sm_f[(pl * G + cg) * 2 * EPV + EPV + e] = p2[e];
+        }
+    }
+    __syncthreads();
+    const int per = G * 2 * EPV;
+    for (int i = threadIdx.x; i < per; i += 256) {
+        float s = 0.f;
+        for (int p = 0; p < PL; ++p) s += sm_f[p * per + i];
+        const int cgi = i / (2 * EPV), r = i - cgi * 2 * EPV, k = r / EPV, e = r - k * EPV;
+        atomicAdd(&acc[((size_t)n * C + cgi * EPV + e) * 2 + k], (double)s);
+    }
+}
+
+// GroupNorm backward coefficients: dz = A*u + B*z + D per (n,c); dgamma/dbeta accumulated over n.
+// One workgroup per image.  m = HW * C/groups elements per group.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const double* __restrict__ acc, int C, int groups, double m,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              float* __restrict__ cA, float* __restrict__ cB, float* __restrict__ cD,
+                                                              double* __restrict__ dgb /* [C][2] */) {
+    extern __shared__ double sm_d[];          // [groups][2]
+    const int n = blockIdx.x;
+    const int cg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        const double mu = mean[n * groups + g], is = invstd[n * groups + g];
+        double t1 = 0.0, t2 = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            const double s1 = acc[((size_t)n * C + c) * 2], s2 = acc[((size_t)n * C + c) * 2 + 1];
+            t1 += (double)gamma[c] * s1;
+            t2 += (double)gamma[c] * is * (s2 - mu * s1);
+        }
+        sm_d[g * 2] = t1 / m;          // c1 = mean(dxhat)
+        sm_d[g * 2 + 1] = t2 / m;      // c2 = mean(dxhat * xhat)
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cg;
+        const double mu = mean[n * groups + g], is = invstd[n * groups + g];
+        const double c1 = sm_d[g * 2], c2 = sm_d[g * 2 + 1];
+        cA[(size_t)n * C + c] = (float)(is * (double)gamma[c]);
+        cB[(size_t)n * C + c] = (float)(-is * is * c2);
+        cD[(size_t)n * C + c] = (float)(-is * c1 + is * is * mu * c2);
+        const double s1 = acc[((size_t)n * C + c) * 2], s2 = acc[((size_t)n * C + c) * 2 + 1];
+        atomicAdd(&dgb[c * 2], is * (s2 - mu * s1));
+        atomicAdd(&dgb[c * 2 + 1], s1);
+    }
+}
+
+// out = A[n][c]*u + B[n][c]*v + D[n][c]
+template <typename T>
+__global__ __launch_bounds__(256) void affine2_kernel(const T* __restrict__ u, const T* __restrict__ v, T* __restrict__ out,
+                                                      const float* __restrict__ cA, const float* __restrict__ cB, const float* __restrict__ cD,
+                                                      long long HW, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    if (pl >= PL) return;
+    const int n = blockIdx.y;
+    float A[EPV], B[EPV], D[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        A[e] = cA[(size_t)n * C + cg * EPV + e]; B[e] = cB[(size_t)n * C + cg * EPV + e]; D[e] = cD[(size_t)n * C + cg * EPV + e];
+    }
+    for (long long p = (long long)blockIdx.x * PL + pl; p < HW; p += (long long)gridDim.x * PL) {
+        const long long pix = (long long)n * HW + p;
+        float fu[EPV], fv[EPV];
+        Vec16<T>::unpack(*(const uint4*)(u + pix * C + cg * EPV), fu);
+        Vec16<T>::unpack(*(const uint4*)(v + pix * C + cg * EPV), fv);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) fu[e] = fmaf(A[e], fu[e], fmaf(B[e], fv[e], D[e]));
+        *(uint4*)(out + pix * C + cg * EPV) = Vec16<T>::pack(fu);
+    }
+}
+
+__global__ void dgb_store_kernel(const double* __restrict__ dgb, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { dgamma[c] = (float)dgb[c * 2]; dbeta[c] = (float)dgb[c * 2 + 1]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int img_grid(long long HW, int PL, int N) {
+    long long g = (HW + PL - 1) / PL;
+    int cap = 2048 / (N > 0 ? N : 1); if (cap < 1) cap = 1;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static int ccheck(int dtype, int C, const char* what) {
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    if (dtype != UNET_F32 && dtype != UNET_BF16) { unet_set_error("%s: bad dtype %d", what, dtype); return -1; }
+    if (C <= 0 || C % 8 != 0 || C / epv > 256) { unet_set_error("%s: C=%d must be a multiple of 8 and at most %d", what, C, 256 * epv); return -1; }
+    return 0;
+}
+
+extern "C" int unet_gn_finalize(const float* stat_rows, int N, int rows_per_image, int C, int groups, long long HW,
+                                const float* gamma, const float* beta, float eps,
+                                float* scale /* [N][C] */, float* shift /* [N][C] */, float* mean /* [N][groups] */, float* invstd,
+                                void* stream) {
+    UNET_CHECK(N > 0 && rows_per_image > 0 && C > 0 && groups > 0 && C % groups == 0, "gn_finalize: bad shape");
+    const size_t lds = sizeof(double) * (2 * (size_t)C + 2 * groups);
+    UNET_CHECK(lds <= 65536, "gn_finalize: C too large");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, stat_rows, rows_per_image, C, groups,
+                       (double)HW * (C / groups), gamma, beta, eps, scale, shift, mean, invstd);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_branch_sum_act(int dtype, int relu, int nb, const void* const* z, const float* const* scale, const float* const* shift,
+                                   int coef_nstride, void* y, int ldy, int yoff, int N, long long HW, int C, void* stream) {
+    if (ccheck(dtype, C, "branch_sum_act")) return -1;
+    UNET_CHECK(nb >= 1 && nb <= MAX_BRANCH, "branch_sum_act: 1..%d branches", MAX_BRANCH);
+    UNET_CHECK(coef_nstride == 0 || coef_nstride == C, "branch_sum_act: coefficient stride must be 0 or C");
+    UNET_CHECK(ldy % 8 == 0 && yoff % 8 == 0, "branch_sum_act: output stride/offset must be multiples of 8");
+    BranchArgs a;
+    for (int b = 0; b < MAX_BRANCH; ++b) {
+        a.z[b] = b < nb ? z[b] : nullptr; a.scale[b] = b < nb ? scale[b] : nullptr; a.shift[b] = b < nb ? shift[b] : nullptr;
+    }
+    a.nb = nb; a.coef_nstride = coef_nstride;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    dim3 grid(img_grid(HW, PL, N), N);
+    hipStream_t s = (hipStream_t)stream;
+#define LB(T, R) hipLaunchKernelGGL((branch_sum_act_kernel<T, R>), grid, dim3(256), 0, s, a, (T*)y, ldy, yoff, HW, C)
+    if (dtype == UNET_BF16) { if (relu) LB(__bf16, true); else LB(__bf16, false); }
+    else { if (relu) LB(float, true); else LB(float, false); }
+#undef LB
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+// GroupNorm backward for one branch: u = upstream gradient already masked by the ReLU, z = the
+// branch's conv output.  acc_ws: N*C*2 + C*2 doubles; coef_ws: 3*N*C floats.
+extern "C" int unet_gn_bwd(int dtype, const void* u, const void* z, void* dz, int N, long long HW, int C, int groups,
+                           const float* gamma, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, double* acc_ws, float* coef_ws, void* stream) {
+    if (ccheck(dtype, C, "gn_bwd")) return -1;
+    UNET_CHECK(groups > 0 && C % groups == 0, "gn_bwd: bad group count");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nacc = (size_t)N * C * 2 + (size_t)C * 2;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * nacc, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    dim3 grid(img_grid(HW, PL, N), N);
+    const size_t lds = (size_t)256 * 2 * epv * sizeof(float);
+    if (dtype == UNET_BF16) hipLaunchKernelGGL((pair_reduce_kernel<__bf16>), grid, dim3(256), lds, s, (const __bf16*)u, (const __bf16*)z, HW, C, acc_ws);
+    else hipLaunchKernelGGL((pair_reduce_kernel<float>), grid, dim3(256), lds, s, (const float*)u, (const float*)z, HW, C, acc_ws);
+    UNET_LAUNCH_CHECK();
+    float* cA = coef_ws; float* cB = coef_ws + (size_t)N * C; float* cD = coef_ws + 2 * (size_t)N * C;
+    double* dgb = acc_ws + (size_t)N * C * 2;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N), dim3(256), sizeof(double) * 2 * groups, s, acc_ws, C, groups,
+                       (double)HW * (C / groups), gamma, mean, invstd, cA, cB, cD, dgb);
+    UNET_LAUNCH_CHECK();
+    if (dtype == UNET_BF16) hipLaunchKernelGGL((affine2_kernel<__bf16>), grid, dim3(256), 0, s, (const __bf16*)u, (const __bf16*)z, (__bf16*)dz, cA, cB, cD, HW, C);
+    else hipLaunchKernelGGL((affine2_kernel<float>), grid, dim3(256), 0, s, (const float*)u, (const float*)z, (float*)dz, cA, cB, cD, HW, C);
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dgb_store_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgb, dgamma, dbeta, C);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}

@@ -88,6 +88,15 @@ class UNetEngine:
             rec.wname, rec.bname, rec.bnp = wname, bname, bnp
         return y, rec
 
+    def block_fwd(self, P, B, prefix, xin, yout, dt, train, save, x_f32=None):
+        """One DoubleConv (models/unet.py:9-16).  Returns (output Act, saved record)."""
+        y1, r1 = self._conv_bn_relu(P, B, prefix, 0, xin, None, dt, train, save, first=x_f32 is not None, x_f32=x_f32)
+        y2, r2 = self._conv_bn_relu(P, B, prefix, 3, y1, yout, dt, train, save)
+        return y2, ((r1, r2) if save else None)
+
+    def block_param_names(self, prefix):
+        return _double_conv_names(prefix)
+
     def forward(self, x: torch.Tensor, P: Dict[str, torch.Tensor], B: Dict[str, torch.Tensor], dt: int,
                 train: bool, save: bool):
         """x: fp32 NCHW [N,Cin,H,W] on the GPU.  Returns (logits fp32 NCHW, saved state or None)."""
@@ -118,20 +127,17 @@ class UNetEngine:
             cat = torch.empty((N, h, w, 2 * f), dtype=ops.torch_dtype(dt), device=dev)
             cats.append(cat)
             p = f"downs.{i}"
-            y1, r1 = self._conv_bn_relu(P, B, p, 0, cur, None, dt, train, save, first=(i == 0), x_f32=x_nhwc if i == 0 else None)
             skip = Act(cat, 0, f)
-            y2, r2 = self._conv_bn_relu(P, B, p, 3, y1, skip, dt, train, save)
+            _, rec = self.block_fwd(P, B, p, cur, skip, dt, train, save, x_f32=x_nhwc if i == 0 else None)
             if save:
-                r2.xin = y1
-                sv.blocks[p] = (r1, r2)
+                sv.blocks[p] = rec
             cur, code = ops.maxpool_fwd(skip)
             if save:
                 sv.codes.append(code)
             h, w = h // 2, w // 2
-        y1, r1 = self._conv_bn_relu(P, B, "bottleneck", 0, cur, None, dt, train, save)
-        cur, r2 = self._conv_bn_relu(P, B, "bottleneck", 3, y1, None, dt, train, save)
+        cur, rec = self.block_fwd(P, B, "bottleneck", cur, None, dt, train, save)
         if save:
-            sv.blocks["bottleneck"] = (r1, r2)
+            sv.blocks["bottleneck"] = rec
         for j, f in enumerate(reversed(self.features)):
             cat = cats[L - 1 - j]
             wt, bt = P[f"ups.{2 * j}.weight"], P[f"ups.{2 * j}.bias"]
@@ -141,10 +147,9 @@ class UNetEngine:
             ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), Act(cat, f, f), 1, 1,
                          2 * f, 4 * f, epi=1)
             p = f"ups.{2 * j + 1}"
-            y1, r1 = self._conv_bn_relu(P, B, p, 0, Act(cat, 0, 2 * f), None, dt, train, save)
-            cur, r2 = self._conv_bn_relu(P, B, p, 3, y1, None, dt, train, save)
+            cur, rec = self.block_fwd(P, B, p, Act(cat, 0, 2 * f), None, dt, train, save)
             if save:
-                sv.blocks[p] = (r1, r2)
+                sv.blocks[p] = rec
         logits = ops.conv_out_fwd(cur, P["final_conv.weight"].detach().view(self.n_classes, -1).contiguous(),
                                   P["final_conv.bias"].detach())
         if save:
@@ -152,8 +157,8 @@ class UNetEngine:
         return logits, sv
 
     # ------------------------------------------------------------------ backward
-    def _block_bwd(self, P, sv, prefix, dy: Act, grads: Dict[str, torch.Tensor], dt, need_dx=True,
-                   split_f: int = 0):
+    def block_bwd(self, P, sv, prefix, dy: Act, grads: Dict[str, torch.Tensor], dt, need_dx=True,
+                  split_f: int = 0):
         """Backward of one DoubleConv.  Returns dx (Act), or (dskip, dup) when split_f > 0."""
         r1, r2 = sv.blocks[prefix]
         dev = dy.buf.device
@@ -213,8 +218,8 @@ class UNetEngine:
         for j in reversed(range(L)):
             f = list(reversed(self.features))[j]
             p = f"ups.{2 * j + 1}"
-            dskip, dup = self._block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
-            emit(_double_conv_names(p))
+            dskip, dup = self.block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
+            emit(self.block_param_names(p))
             dskips[L - 1 - j] = dskip
             xin = sv.up_in[j]
             tname = f"ups.{2 * j}"
@@ -224,11 +229,11 @@ class UNetEngine:
             ops.convT_dgrad(dup, self.packed(tname + ".weight", P[tname + ".weight"], 3, dt), xin.C, dcur)
             del dup
             emit([tname + ".weight", tname + ".bias"])
-        dcur = self._block_bwd(P, sv, "bottleneck", dcur, grads, dt)
-        emit(_double_conv_names("bottleneck"))
+        dcur = self.block_bwd(P, sv, "bottleneck", dcur, grads, dt)
+        emit(self.block_param_names("bottleneck"))
         for i in reversed(range(L)):
             dy2 = ops.maxpool_bwd(dcur, sv.codes[i], dskips[i])
             dskips[i] = None
-            dcur = self._block_bwd(P, sv, f"downs.{i}", dy2, grads, dt, need_dx=(i > 0))
-            emit(_double_conv_names(f"downs.{i}"))
+            dcur = self.block_bwd(P, sv, f"downs.{i}", dy2, grads, dt, need_dx=(i > 0))
+            emit(self.block_param_names(f"downs.{i}"))
         return grads

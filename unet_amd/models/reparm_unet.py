@@ -1,0 +1,174 @@
+"""ReparamUNet with the reference's constructors, registration order and state_dict, on HIP kernels.
+
+Mirrors /root/reference/models/reparm_unet.py:10-234.  Children are parameter containers; forward runs
+unet_amd.rep_engine.RepUNetEngine.
+
+The reference's switch_to_deploy() raises AttributeError as shipped, because getBN returns GroupNorm
+(:17-25) while mergeBN reads running_var (:28-31).  Decision: the constructor
+keeps its signature and gains an optional `norm` kwarg: "group" (default, as shipped) or "batch" (the
+author's commented-out BatchNorm2d(momentum=0.01) variant, :14-15).  The fold is defined, HIP-executed
+and bit-exact-tested for "batch"; for "group" it raises a clear error (GroupNorm statistics depend on
+the input, there is nothing to fold).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..rep_engine import RepUNetEngine
+from .unet import _UNetFn, resolve_dtype
+
+
+def getConv2D(in_channels, out_channels, kernel_size=(3, 3), stride=1, padding=0, groups=1, bias=True):
+    return nn.Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size, stride=stride,
+                     padding=padding, groups=groups, bias=bias)
+
+
+def getBN(channels, eps=1e-5, momentum=None, affine=True, norm="group"):
+    if norm == "batch":
+        return nn.BatchNorm2d(num_features=channels, eps=eps, momentum=0.01 if momentum is None else momentum, affine=affine)
+    return nn.GroupNorm(num_groups=min(8, channels), num_channels=channels, eps=eps, affine=affine)
+
+
+def _bn_tuple(bn):
+    return (bn.weight.detach().contiguous(), bn.bias.detach().contiguous(), bn.running_mean.contiguous(), bn.running_var.contiguous())
+
+
+class AsymmConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, depthwise=False, norm="group"):
+        super().__init__()
+        if depthwise or stride != 1:
+            raise NotImplementedError("unet_amd AsymmConvBlock: stride 1, groups 1 only (what ReparamUNet uses)")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.padding, self.stride, self.depthwise = kernel_size, padding, stride, depthwise
+        self.norm = norm
+        self.mergedFlag = False
+        self.mergedConv = None
+        k = kernel_size
+        self.convVe1 = getConv2D(in_channels, out_channels, (k, 1), stride, [padding, 0], bias=False)
+        self.bnVe1 = getBN(out_channels, norm=norm)
+        self.convHo1 = getConv2D(in_channels, out_channels, (1, k), stride, [0, padding], bias=False)
+        self.bnHo1 = getBN(out_channels, norm=norm)
+        self.convSq = getConv2D(in_channels, out_channels, (k, k), stride, [padding, padding], bias=False)
+        self.bnSq = getBN(out_channels, norm=norm)
+
+    def forward(self, x):
+        raise ops.UNetHipError("AsymmConvBlock is executed by ReparamUNet.forward on the HIP engine")
+
+    def mergeAsyKernels(self):
+        if self.mergedFlag:
+            return
+        if self.norm != "batch":
+            raise ops.UNetHipError("the fold needs running statistics: build ReparamUNet(..., norm='batch'); "
+                                   "GroupNorm (the shipped default) is input-dependent and cannot be folded")
+        w, b = ops.fold_asymm(self.kernel_size, self.convSq.weight.detach().contiguous(), self.convVe1.weight.detach().contiguous(),
+                              self.convHo1.weight.detach().contiguous(), _bn_tuple(self.bnSq), _bn_tuple(self.bnVe1),
+                              _bn_tuple(self.bnHo1), self.bnSq.eps)
+        k = self.kernel_size
+        self.mergedConv = getConv2D(self.in_channels, self.out_channels, (k, k), self.stride, [self.padding, self.padding], bias=True)
+        self.mergedConv.weight.data = w
+        self.mergedConv.bias.data = b
+        self.mergedFlag = True
+        for attr in ["convVe1", "bnVe1", "convHo1", "bnHo1", "convSq", "bnSq"]:
+            if hasattr(self, attr):
+                delattr(self, attr)
+
+
+class MultiConvBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_sizes, stride, depthwise=False, norm="group"):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_sizes = sorted(kernel_sizes)
+        self.stride, self.depthwise = stride, depthwise
+        self.mergedFlag = False
+        self.mergedConv = None
+        self.conv_list = nn.ModuleList()
+        for kernel in self.kernel_sizes:
+            self.conv_list.append(AsymmConvBlock(in_channels, out_channels, kernel, stride, kernel // 2, depthwise, norm=norm))
+
+    def forward(self, x):
+        raise ops.UNetHipError("MultiConvBlock is executed by ReparamUNet.forward on the HIP engine")
+
+    def mergeMulKernels(self):
+        if self.mergedFlag:
+            return
+        for block in self.conv_list:
+            block.mergeAsyKernels()
+        target_w = self.conv_list[-1].mergedConv.weight.data.clone()
+        target_b = self.conv_list[-1].mergedConv.bias.data.clone()
+        for i in range(len(self.conv_list) - 1):
+            ops.fold_embed_add(target_w, self.conv_list[i].mergedConv.weight.data, target_b, self.conv_list[i].mergedConv.bias.data)
+        max_k = self.kernel_sizes[-1]
+        self.mergedConv = getConv2D(self.in_channels, self.out_channels, (max_k, max_k), self.stride, [max_k // 2, max_k // 2], bias=True)
+        self.mergedConv.weight.data = target_w
+        self.mergedConv.bias.data = target_b
+        self.mergedFlag = True
+        if hasattr(self, "conv_list"):
+            delattr(self, "conv_list")
+
+
+class ReparamDoubleConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_sizes=[3], norm="group"):
+        super().__init__()
+        self.reparam_conv = nn.Sequential(
+            MultiConvBlock(in_channels, out_channels, kernel_sizes, stride=1, depthwise=False, norm=norm),
+            nn.ReLU(inplace=True),
+            MultiConvBlock(out_channels, out_channels, kernel_sizes, stride=1, depthwise=False, norm=norm),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):
+        raise ops.UNetHipError("ReparamDoubleConv is executed by ReparamUNet.forward on the HIP engine")
+
+
+class ReparamUNet(nn.Module):
+    def __init__(self, in_channels=1, n_classes=3, features=[64, 128, 256, 512], kernel_sizes=[3], norm="group"):
+        super().__init__()
+        if norm not in ("group", "batch"):
+            raise ValueError("norm must be 'group' (as shipped) or 'batch' (foldable variant)")
+        features = list(features)
+        self.ups = nn.ModuleList()
+        self.downs = nn.ModuleList()
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.kernel_sizes = kernel_sizes
+        self.norm = norm
+        cin = in_channels
+        for feature in features:
+            self.downs.append(ReparamDoubleConv(cin, feature, kernel_sizes, norm))
+            cin = feature
+        for feature in reversed(features):
+            self.ups.append(nn.ConvTranspose2d(feature * 2, feature, kernel_size=2, stride=2))
+            self.ups.append(ReparamDoubleConv(feature * 2, feature, kernel_sizes, norm))
+        self.bottleneck = ReparamDoubleConv(features[-1], features[-1] * 2, kernel_sizes, norm)
+        self.final_conv = nn.Conv2d(features[0], n_classes, kernel_size=1)
+        for f in features:
+            if f % 8:
+                raise ValueError(f"unet_amd needs every feature width to be a multiple of 8 (got {features})")
+        if in_channels > 4 or not 1 <= n_classes <= 8:
+            raise ValueError("unet_amd serves in_channels <= 4 and 1..8 classes")
+        self._engine = RepUNetEngine(features, in_channels, n_classes, kernel_sizes, norm)
+        self.compute_dtype = None
+        self._grad_hook = None
+
+    @property
+    def _param_names(self):
+        return [n for n, _ in self.named_parameters()]
+
+    def forward(self, x, current_epoch=None):
+        params = [p for _, p in self.named_parameters()]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
+
+    def switch_to_deploy(self):
+        """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels)."""
+        print("[ReparamUNet] Switching to deploy mode (fusing kernels)...")
+        for module in list(self.modules()):
+            if isinstance(module, MultiConvBlock):
+                module.mergeMulKernels()
+        self._engine._packed.clear()
+        print("[ReparamUNet] Fusion complete.")
+
+
+def build_reparam_unet(**kwargs):
+    if "kernel_sizes" not in kwargs:
+        kwargs["kernel_sizes"] = [3]
+    return ReparamUNet(**kwargs)

@@ -110,7 +110,7 @@ def pack_weights(w: torch.Tensor, mode: int, dt: int) -> torch.Tensor:
 def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act, kh: int, kw: int,
              Cin: int, Cout: int, stats: bool = False, stride_h: int = 1, epi: int = 0,
              pad_h: Optional[int] = None, pad_w: Optional[int] = None,
-             y2: Optional[Act] = None, csplit: int = 0):
+             y2: Optional[Act] = None, csplit: int = 0, accumulate: bool = False, relu: bool = False):
     """y = conv(x) (+bias).  Returns the BN partial-stat rows tensor when stats=True.
     epi=1: 1x1 conv with Cout = 4*C and 2x2 pixel shuffle into y (ConvTranspose2d forward)."""
     x.check(); y.check()
@@ -148,7 +148,8 @@ def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act
     check(lib().unet_conv_fwd(dt, kh, kw, stride_h, epi, _p(x.buf), _p(wpacked), _p(bias), _p(y.buf), _p(rows),
                               x.N, x.H, x.W, Cin, x.ld, x.off, Hout, Wout, Cout, y.ld, y.off, ph, pw,
                               _p(y2.buf) if y2 is not None else None, y2.ld if y2 is not None else 0,
-                              y2.off if y2 is not None else 0, csplit if y2 is not None else 0, _stream()), "conv_fwd")
+                              y2.off if y2 is not None else 0, csplit if y2 is not None else 0,
+                              (1 if accumulate else 0) | (2 if relu else 0), _stream()), "conv_fwd")
     return rows
 
 
@@ -427,3 +428,87 @@ def seg_counts(pred: torch.Tensor, target: torch.Tensor, K: int) -> torch.Tensor
     counts = torch.empty(66, dtype=torch.int64, device=pred.device)
     check(lib().unet_seg_counts(_p(pred), _p(target), pred.numel(), K, _p(counts), _stream()), "seg_counts")
     return counts
+
+
+# ----------------------------------------------------------------------------- RepUNet
+
+@dataclass
+class GNState:
+    scale: torch.Tensor      # [N][C]
+    shift: torch.Tensor      # [N][C]
+    mean: torch.Tensor       # [N][groups]
+    invstd: torch.Tensor
+    groups: int
+
+
+def gn_finalize(rows: torch.Tensor, N: int, HW: int, gamma, beta, groups: int, eps: float = 1e-5) -> GNState:
+    """per-image conv statistics rows [N*rpi][C][2] -> GroupNorm coefficients."""
+    nrows, C, _ = rows.shape
+    if nrows % N:
+        raise UNetHipError("gn_finalize: statistics rows are not grouped per image")
+    dev = rows.device
+    coef = torch.empty((2, N, C), dtype=torch.float32, device=dev)
+    ms = torch.empty((2, N, groups), dtype=torch.float32, device=dev)
+    check(lib().unet_gn_finalize(_p(rows), N, nrows // N, C, groups, HW, _p(gamma), _p(beta), float(eps),
+                                 _p(coef[0]), _p(coef[1]), _p(ms[0]), _p(ms[1]), _stream()), "gn_finalize")
+    return GNState(coef[0], coef[1], ms[0], ms[1], groups)
+
+
+def branch_sum_act(zs, scales, shifts, per_sample: bool, y: Act, relu=True):
+    """y = act(sum_b z_b*scale_b + shift_b); z_b dense Acts of y's shape."""
+    import ctypes
+    y.check()
+    nb = len(zs)
+    for z in zs:
+        z.check()
+        if z.off != 0 or z.ld != z.C or z.C != y.C or z.M != y.M or z.dt != y.dt:
+            raise UNetHipError("branch_sum_act: branch tensors must be dense and shaped like the output")
+    C = y.C
+    for s in list(scales) + list(shifts):
+        if s.dtype != torch.float32 or s.numel() != (y.N * C if per_sample else C):
+            raise UNetHipError("branch_sum_act: coefficient shape mismatch")
+    PA = ctypes.c_void_p * nb
+    check(lib().unet_branch_sum_act(y.dt, 1 if relu else 0, nb, PA(*[z.buf.data_ptr() for z in zs]),
+                                    PA(*[s.data_ptr() for s in scales]), PA(*[s.data_ptr() for s in shifts]),
+                                    C if per_sample else 0, _p(y.buf), y.ld, y.off, y.N, y.H * y.W, C, _stream()),
+          "branch_sum_act")
+
+
+def gn_bwd(u: Act, z: Act, st: GNState, gamma: torch.Tensor):
+    """-> (dz dense Act, dgamma, dbeta)."""
+    u.check(); z.check()
+    if u.off or z.off or u.ld != u.C or z.ld != z.C or u.C != z.C or u.M != z.M:
+        raise UNetHipError("gn_bwd: dense tensors of equal shape expected")
+    N, C, dev = z.N, z.C, z.buf.device
+    dz = dense(z.N, z.H, z.W, C, z.dt, dev)
+    g = torch.empty((2, C), dtype=torch.float32, device=dev)
+    acc = torch.empty(N * C * 2 + C * 2, dtype=torch.float64, device=dev)
+    coef = torch.empty(3 * N * C, dtype=torch.float32, device=dev)
+    check(lib().unet_gn_bwd(z.dt, _p(u.buf), _p(z.buf), _p(dz.buf), N, z.H * z.W, C, st.groups, _p(gamma), _p(st.mean),
+                            _p(st.invstd), _p(g[0]), _p(g[1]), _p(acc), _p(coef), _stream()), "gn_bwd")
+    return dz, g[0], g[1]
+
+
+def fold_asymm(k, w_sq, w_ve, w_ho, bn_sq, bn_ve, bn_ho, eps=1e-5):
+    """One AsymmConvBlock -> (weight (O,I,k,k), bias (O)); bn_* = (weight, bias, running_mean, running_var)."""
+    ts = [w_sq, w_ve, w_ho, *bn_sq, *bn_ve, *bn_ho]
+    _need_cuda(*ts)
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise UNetHipError("fold: contiguous fp32 tensors expected")
+    O, I = w_sq.shape[0], w_sq.shape[1]
+    if tuple(w_sq.shape) != (O, I, k, k) or tuple(w_ve.shape) != (O, I, k, 1) or tuple(w_ho.shape) != (O, I, 1, k):
+        raise UNetHipError("fold: branch kernel shapes do not match")
+    out_w = torch.empty((O, I, k, k), dtype=torch.float32, device=w_sq.device)
+    out_b = torch.empty((O,), dtype=torch.float32, device=w_sq.device)
+    check(lib().unet_fold_asymm(k, O, I, _p(w_sq), _p(w_ve), _p(w_ho), *[_p(t) for t in bn_sq], *[_p(t) for t in bn_ve],
+                                *[_p(t) for t in bn_ho], float(eps), _p(out_w), _p(out_b), _stream()), "fold_asymm")
+    return out_w, out_b
+
+
+def fold_embed_add(target_w, src_w, target_b, src_b):
+    K, k = target_w.shape[-1], src_w.shape[-1]
+    O, I = target_w.shape[0], target_w.shape[1]
+    if tuple(src_w.shape) != (O, I, k, k) or tuple(target_w.shape) != (O, I, K, K):
+        raise UNetHipError("fold: cannot embed, shape mismatch")
+    check(lib().unet_fold_embed_add(K, k, O, I, _p(target_w), _p(src_w), _p(target_b), _p(src_b), _stream()), "fold_embed_add")
