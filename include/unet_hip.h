@@ -50,7 +50,7 @@ int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
 /* weight gradient of the same convolutions (autograd of models/unet.py:10,13,35).
  * slab: workspace of unet_conv_wgrad_splits() * kh*kw*Cout*Cin floats.
  * dw[o][i][tap] for tap in [dw_tap0, dw_tap0+kh*kw) of dw_taps taps per (o,i). */
-int unet_conv_wgrad_splits(int dtype, int N, int Hout, int Wout, int Cin, int Cout);
+int unet_conv_wgrad_splits(int dtype, int kh, int kw, int stride_h, int N, int Hout, int Wout, int Cin, int Cout);
 int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
                     const void* dz, const void* x, float* slab, float* dw, int accumulate,
                     int dw_taps, int dw_tap0,

@@ -16,15 +16,11 @@
 // nn.ConvTranspose2d(k=2,s=2) weight grad (models/unet.py:35) through the [N,2H,W,2C] view.
 #include "common.h"
 
-struct WgradArgs {
-    const void* dz;   // [N,Hout,Wout,lddz] (+dzoff), Cout channels
-    const void* x;    // [N,Hin,Win,ldx]   (+xoff),  Cin channels
-    float* slab;      // [nsplit][KH*KW][Cout][Cin]
-    int N, Hin, Win, Cin, ldx, xoff;
-    int Hout, Wout, Cout, lddz, dzoff;
-    int pad_h, pad_w, tiles_h, tiles_w;
-    int tiles_total, tiles_per_split;
-};
+#include "wgrad_args.h"
+
+// bf16 path (conv_wgrad2.hip)
+int wgrad2_splits(int kh, int kw, int sh, int N, int Hout, int Wout, int Cin, int Cout);
+int dispatch_wgrad2(int kh, int kw, int sh, const WgradArgs& a, hipStream_t s, int nsplit);
 
 // 128-byte-record LDS image: record `pix`, byte b (b<128).  The XOR keeps the eight 32-byte pieces
 // that one 32-lane half of a transposing read touches on distinct banks.
@@ -236,8 +232,9 @@ static int dispatch_wgrad(int kh, int kw, int sh, const WgradArgs& a, hipStream_
 
 // Number of split-K slabs unet_conv_wgrad will write for this problem (the caller sizes the
 // workspace as nsplit * kh*kw * Cout * Cin floats).
-extern "C" int unet_conv_wgrad_splits(int dtype, int N, int Hout, int Wout, int Cin, int Cout) {
-    const int ct = dtype == UNET_BF16 ? 64 : 32;
+extern "C" int unet_conv_wgrad_splits(int dtype, int kh, int kw, int stride_h, int N, int Hout, int Wout, int Cin, int Cout) {
+    if (dtype == UNET_BF16) return wgrad2_splits(kh, kw, stride_h, N, Hout, Wout, Cin, Cout);
+    const int ct = 32;
     const int tiles = N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
     const int blocks = ((Cout + ct - 1) / ct) * ((Cin + ct - 1) / ct);
     int want = (1024 + blocks - 1) / blocks;          // aim for ~4 workgroups per CU
@@ -270,10 +267,10 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
     a.pad_h = pad_h; a.pad_w = pad_w;
     a.tiles_h = (Hout + 7) / 8; a.tiles_w = (Wout + 31) / 32;
     a.tiles_total = N * a.tiles_h * a.tiles_w;
-    const int nsplit = unet_conv_wgrad_splits(dtype, N, Hout, Wout, Cin, Cout);
+    const int nsplit = unet_conv_wgrad_splits(dtype, kh, kw, stride_h, N, Hout, Wout, Cin, Cout);
     a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == UNET_BF16 ? dispatch_wgrad<__bf16>(kh, kw, stride_h, a, s, nsplit)
+    int rc = dtype == UNET_BF16 ? dispatch_wgrad2(kh, kw, stride_h, a, s, nsplit)
                                 : dispatch_wgrad<float>(kh, kw, stride_h, a, s, nsplit);
     if (rc) return rc;
     if (dw == nullptr) return 0;    // caller reduces the slabs itself (ConvTranspose2d layout)

@@ -1,0 +1,278 @@
+// bf16 weight gradient, second generation (gfx950): LDS-DMA double-buffered split-K GEMM.
+//
+//   dW[tap][co][ci] = sum over output pixels m of  dz[m][co] * x[SH*m + tap][ci]
+//
+// Same math and slab layout as conv_wgrad.hip (which keeps the exact-f32 path); what changes is how
+// the operands reach the matrix cores:
+//   * one 512-thread workgroup per CU.  Waves 0-3 and 4-7 each own the whole CT x CT x taps block
+//     of accumulators but take alternate halves of every K tile (pixel rows), so each SIMD holds two
+//     waves that hide each other's LDS latency; the two halves are summed through LDS at the end.
+//   * the dz tile and the x halo tile are written straight into LDS by global_load_lds_dwordx4
+//     (no staging registers, no ds_write), into one of two stages: tile t+1 is in flight while
+//     tile t is multiplied; one barrier per tile.
+//   * zero padding (image border, ragged tiles, channel tails): the lane's SOURCE address is pointed
+//     at a 16-byte block of zeros, the LDS destination being lane-linear.
+//   * LDS images are pixel-major records of CT channels; the bank swizzle is a function of the pixel
+//     COLUMN only and is applied to the source address (DMA side) and to the transposing reads, so
+//     every fragment address is a per-lane base plus a compile-time immediate.
+//   * workgroups are ordered channel-block fastest, so the workgroups resident at one time read the
+//     same pixel range and share it through L2 / Infinity Cache.
+#include "common.h"
+#include "wgrad_args.h"
+
+__device__ __attribute__((aligned(64))) uint4 g_wgrad_zero[4];   // source of every padded 16-byte piece
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void glb_void;
+
+// REC = bytes per pixel record (128: 64 channels, 256: 128 channels).  XOR, in bytes, of the record's
+// 32-byte pieces: keeps the eight pieces that one 32-lane half of ds_read_b64_tr_b16 touches (pixel
+// columns c..c+3 and c+8..c+11, same channel bytes) on distinct banks.
+template <int REC> __device__ __forceinline__ int swz_bytes(int col) {
+    if constexpr (REC == 128) return (((col >> 1) & 1) << 6) | (((col >> 3) & 1) << 5);
+    else return ((col & 3) << 5) | (((col >> 3) & 1) << 7);
+}
+
+__device__ __forceinline__ uint4 tr_frag2(const char* lo_addr, const char* hi_addr) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lo_addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)hi_addr);
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+template <int KH, int KW, int SH, int WT, int TH>
+struct Wg2Cfg {
+    static constexpr int TW = 32;
+    static constexpr int CT = 32 * WT;                 // channels per block side
+    static constexpr int REC = CT * 2;                 // bytes per pixel record
+    static constexpr int SLOTS = REC / 16;
+    static constexpr int RPP = 1024 / REC;             // records per DMA piece (one wave instruction = 1 KiB)
+    static constexpr int HH = (TH - 1) * SH + KH, HWD = TW - 1 + KW;
+    static constexpr int DZ_REC = TH * TW, X_REC = HH * HWD;
+    static constexpr int DZ_PIECES = DZ_REC / RPP, X_PIECES = (X_REC + RPP - 1) / RPP;
+    static constexpr int DZ_BYTES = DZ_PIECES * 1024, X_BYTES = X_PIECES * 1024;
+    static constexpr int STAGE = DZ_BYTES + X_BYTES;
+    static constexpr int NT = KH * KW;
+    static constexpr int NACC4 = NT * WT * WT;         // f32x4 accumulators per wave
+    static constexpr int RED_BYTES = NACC4 * 4 * 64 * 16;
+    static constexpr int SMEM = (2 * STAGE > RED_BYTES) ? 2 * STAGE : RED_BYTES;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+    static_assert(TH % 2 == 0, "the two wave groups split the tile rows");
+    static_assert((HWD * REC) % 256 == 0, "row pitch must keep the bank phase");
+};
+
+template <int KH, int KW, int SH, int WT, int TH>
+__global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan) {
+    using C = Wg2Cfg<KH, KW, SH, WT, TH>;
+    constexpr int REC = C::REC, SLOTS = C::SLOTS, RPP = C::RPP, HWD = C::HWD, NT = C::NT, CT = C::CT;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave >> 2, w4 = wave & 3;
+    const int g = lane >> 4, l15 = lane & 15;
+
+    // channel block fastest: resident workgroups share the pixel range
+    const int chan = blockIdx.x % nchan, split = blockIdx.x / nchan;
+    const int co0 = (chan / nchan_ci) * CT, ci0 = (chan % nchan_ci) * CT;
+    const int wco = (w4 >> 1) * (16 * WT), wci = (w4 & 1) * (16 * WT);
+
+    f32x4 acc[NT][WT][WT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane fragment bases (bytes inside the dz / x image); rows add compile-time immediates
+    int a_lo[WT], a_hi[WT], b_lo[KW][WT], b_hi[KW][WT];
+    {
+        const int q = l15 >> 2, p = l15 & 3;
+#pragma unroll
+        for (int i = 0; i < WT; ++i) {
+            const int col = 8 * g + q, chb = (wco + 16 * i) * 2;
+            a_lo[i] = col * REC + (chb ^ swz_bytes<REC>(col)) + 8 * p;
+            a_hi[i] = (col + 4) * REC + (chb ^ swz_bytes<REC>(col + 4)) + 8 * p;
+        }
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int col = kw + 8 * g + q, chb = (wci + 16 * j) * 2;
+                b_lo[kw][j] = C::DZ_BYTES + col * REC + (chb ^ swz_bytes<REC>(col)) + 8 * p;
+                b_hi[kw][j] = C::DZ_BYTES + (col + 4) * REC + (chb ^ swz_bytes<REC>(col + 4)) + 8 * p;
+            }
+    }
+
+    const __bf16* __restrict__ dzp = (const __bf16*)a.dz + a.dzoff + co0;
+    const __bf16* __restrict__ xp = (const __bf16*)a.x + a.xoff + ci0;
+    const char* zero = (const char*)g_wgrad_zero;
+
+    const int t_begin = split * a.tiles_per_split;
+    const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
+
+    // One tile's DMA: every wave issues its share of the 1-KiB pieces of both images.
+    auto issue = [&](int tile, int stage_off) {
+        int t = tile;
+        const int tw_i = t % a.tiles_w; t /= a.tiles_w;
+        const int th_i = t % a.tiles_h;
+        const int n = t / a.tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * C::TW;
+        const int rl = lane / SLOTS, s = lane % SLOTS;
+        {
+            const char* base = (const char*)(dzp + (size_t)n * a.Hout * a.Wout * a.lddz);
+#pragma unroll
+            for (int i = 0; i < (C::DZ_PIECES + 7) / 8; ++i) {
+                const int piece = wave + 8 * i;
+                if (piece < C::DZ_PIECES) {
+                    const int R = piece * RPP + rl;
+                    const int r = R >> 5, c = R & 31;
+                    const int q = s ^ (swz_bytes<REC>(c) >> 4);
+                    const int ho = h0 + r, wo = w0 + c;
+                    const bool ok = ho < a.Hout && wo < a.Wout && (co0 + q * 8) < a.Cout;
+                    const char* src = ok ? base + ((unsigned)((ho * a.Wout + wo) * a.lddz + q * 8) * 2u) : zero;
+                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem + stage_off + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+        {
+            const char* base = (const char*)(xp + (size_t)n * a.Hin * a.Win * a.ldx);
+#pragma unroll
+            for (int i = 0; i < (C::X_PIECES + 7) / 8; ++i) {
+                const int piece = wave + 8 * i;
+                if (piece < C::X_PIECES) {
+                    const int R = piece * RPP + rl;
+                    const int hr = R / HWD, hc = R - hr * HWD;
+                    const int q = s ^ (swz_bytes<REC>(hc) >> 4);
+                    const int row = h0 * SH + hr - a.pad_h, col = w0 + hc - a.pad_w;
+                    const bool ok = R < C::X_REC && row >= 0 && row < a.Hin && col >= 0 && col < a.Win && (ci0 + q * 8) < a.Cin;
+                    const char* src = ok ? base + ((unsigned)((row * a.Win + col) * a.ldx + q * 8) * 2u) : zero;
+                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem + stage_off + C::DZ_BYTES + piece * 1024), 16, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (t_begin < t_end) issue(t_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (tile + 1 < t_end) issue(tile + 1, (cur ^ 1) * C::STAGE);
+        const char* img = smem + cur * C::STAGE;
+        // this wave group's half of the tile rows; K-step = one row of 32 pixels
+#pragma unroll
+        for (int rr = 0; rr < TH / 2; ++rr) {
+            const int r = kg * (TH / 2) + rr;           // wave-uniform, folded into the base below
+            const char* ia = img + r * (32 * REC);
+            const char* ib = img + r * (SH * HWD * REC);
+            uint4 fa[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) fa[i] = tr_frag2(ia + a_lo[i], ia + a_hi[i]);
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) {
+                const int kh = t2 / KW, kw = t2 % KW;
+                uint4 fb[WT];
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    fb[j] = tr_frag2(ib + b_lo[kw][j] + kh * HWD * REC, ib + b_hi[kw][j] + kh * HWD * REC);
+#pragma unroll
+                for (int i = 0; i < WT; ++i)
+#pragma unroll
+                    for (int j = 0; j < WT; ++j)
+                        acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[t2][i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
+        __syncthreads();                                    // ... everyone's; and everyone is done reading `cur`
+        cur ^= 1;
+    }
+
+    // ---- sum the two wave groups through LDS: [acc4][wave4][lane] float4 ----
+    f32x4* red = (f32x4*)smem;
+    if (kg == 1) {
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    red[(((t2 * WT + i) * WT + j) * 4 + w4) * 64 + lane] = acc[t2][i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;
+
+    // ---- store the partial block: D[row = co = 4g+reg][col = ci = l15] ----
+    float* slab = a.slab + (size_t)split * NT * a.Cout * a.Cin;
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const f32x4 o = red[(((t2 * WT + i) * WT + j) * 4 + w4) * 64 + lane];
+                const int ci = ci0 + wci + 16 * j + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wco + 16 * i + 4 * g + r;
+                    if (co < a.Cout && ci < a.Cin) slab[((size_t)t2 * a.Cout + co) * a.Cin + ci] = acc[t2][i][j][r] + o[r];
+                }
+            }
+}
+
+template <int KH, int KW, int SH, int WT, int TH>
+static int launch_wgrad2(WgradArgs a, hipStream_t stream, int nsplit) {
+    using C = Wg2Cfg<KH, KW, SH, WT, TH>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    a.tiles_h = (a.Hout + TH - 1) / TH; a.tiles_w = (a.Wout + 31) / 32;
+    a.tiles_total = a.N * a.tiles_h * a.tiles_w;
+    a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
+    const int nco = (a.Cout + C::CT - 1) / C::CT, nci = (a.Cin + C::CT - 1) / C::CT;
+    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH>), dim3((unsigned)(nsplit * nco * nci)), dim3(512), C::SMEM, stream,
+                       a, nci, nco * nci);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+// geometry of the bf16 path for (kh, kw, stride): channel tile and rows per K tile
+void wgrad2_geometry(int kh, int kw, int sh, int* ct, int* th) {
+    if (sh == 2) { *ct = 128; *th = 2; } else { *ct = 64; *th = 8; }
+}
+
+int wgrad2_splits(int kh, int kw, int sh, int N, int Hout, int Wout, int Cin, int Cout) {
+    int ct, th;
+    wgrad2_geometry(kh, kw, sh, &ct, &th);
+    const int tiles = N * ((Hout + th - 1) / th) * ((Wout + 31) / 32);
+    const int blocks = ((Cout + ct - 1) / ct) * ((Cin + ct - 1) / ct);
+    int want = (256 + blocks - 1) / blocks;           // one 512-thread workgroup per CU
+    if (want > tiles) want = tiles;
+    if (want < 1) want = 1;
+    const int per = (tiles + want - 1) / want;
+    return (tiles + per - 1) / per;
+}
+
+int dispatch_wgrad2(int kh, int kw, int sh, const WgradArgs& a, hipStream_t s, int nsplit) {
+    if (sh == 2) {
+        UNET_CHECK(kh == 2 && kw == 1, "stride-2 form is the 2x1 convT view only");
+        return launch_wgrad2<2, 1, 2, 4, 2>(a, s, nsplit);
+    }
+    if (kh == 3 && kw == 3) return launch_wgrad2<3, 3, 1, 2, 8>(a, s, nsplit);
+    if (kh == 1 && kw == 1) return launch_wgrad2<1, 1, 1, 2, 8>(a, s, nsplit);
+    if (kh == 3 && kw == 1) return launch_wgrad2<3, 1, 1, 2, 8>(a, s, nsplit);
+    if (kh == 1 && kw == 3) return launch_wgrad2<1, 3, 1, 2, 8>(a, s, nsplit);
+    if (kh == 5 && kw == 1) return launch_wgrad2<5, 1, 1, 2, 8>(a, s, nsplit);
+    if (kh == 1 && kw == 5) return launch_wgrad2<1, 5, 1, 2, 8>(a, s, nsplit);
+    unet_set_error("unsupported wgrad kernel %dx%d stride %d", kh, kw, sh);
+    return -1;
+}

@@ -168,7 +168,7 @@ def conv_wgrad(dz: Act, x: Act, kh: int, kw: int, ws: Workspace, dw: Optional[to
         raise UNetHipError("wgrad: batch mismatch")
     nt = kh * kw
     dw_taps = nt if dw_taps is None else dw_taps
-    nsplit = lib().unet_conv_wgrad_splits(dt, dz.N, dz.H, dz.W, Cin, Cout)
+    nsplit = lib().unet_conv_wgrad_splits(dt, kh, kw, stride_h, dz.N, dz.H, dz.W, Cin, Cout)
     slab = ws.get_slab(nsplit * nt * Cout * Cin)
     if reduce and dw is None:
         dw = torch.empty((Cout, Cin, dw_taps), dtype=torch.float32, device=x.buf.device)
