@@ -4,9 +4,9 @@
 //
 // Same math and slab layout as conv_wgrad.hip (which keeps the exact-f32 path); what changes is how
 // the operands reach the matrix cores:
-//   * one 512-thread workgroup per CU.  Waves 0-3 and 4-7 each own the whole CT x CT x taps block
-//     of accumulators but take alternate halves of every K tile (pixel rows), so each SIMD holds two
-//     waves that hide each other's LDS latency; the two halves are summed through LDS at the end.
+//   * one 512-thread workgroup per CU: 8 waves as 2 (co) x 4 (ci), each owning a (CT/2) x (CT/4) x taps
+//     block of accumulators (72 registers for 3x3), so each SIMD holds two waves that hide each
+//     other's LDS latency and there is room to request the next tap's fragments ahead of the MFMAs.
 //   * the dz tile and the x halo tile are written straight into LDS by global_load_lds_dwordx4
 //     (no staging registers, no ds_write), into one of two stages: tile t+1 is in flight while
 //     tile t is multiplied; one barrier per tile.
@@ -54,11 +54,10 @@ struct Wg2Cfg {
     static constexpr int DZ_BYTES = DZ_PIECES * 1024, X_BYTES = X_PIECES * 1024;
     static constexpr int STAGE = DZ_BYTES + X_BYTES;
     static constexpr int NT = KH * KW;
-    static constexpr int NACC4 = NT * WT * WT;         // f32x4 accumulators per wave
-    static constexpr int RED_BYTES = NACC4 * 4 * 64 * 16;
-    static constexpr int SMEM = (2 * STAGE > RED_BYTES) ? 2 * STAGE : RED_BYTES;
+    static constexpr int WM = WT, WN = WT / 2;         // wave tile in 16-channel units: (16*WM) co x (16*WN) ci
+    static constexpr int SMEM = 2 * STAGE;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
-    static_assert(TH % 2 == 0, "the two wave groups split the tile rows");
+    static_assert(WT % 2 == 0, "wave grid is 2 (co) x 4 (ci)");
     static_assert((HWD * REC) % 256 == 0, "row pitch must keep the bank phase");
 };
 
@@ -71,28 +70,28 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kg = wave >> 2, w4 = wave & 3;
     const int g = lane >> 4, l15 = lane & 15;
+    constexpr int WM = C::WM, WN = C::WN;
 
     // channel block fastest: resident workgroups share the pixel range
     const int chan = blockIdx.x % nchan, split = blockIdx.x / nchan;
     const int co0 = (chan / nchan_ci) * CT, ci0 = (chan % nchan_ci) * CT;
-    const int wco = (w4 >> 1) * (16 * WT), wci = (w4 & 1) * (16 * WT);
+    const int wco = (wave >> 2) * (16 * WM), wci = (wave & 3) * (16 * WN);
 
-    f32x4 acc[NT][WT][WT];
+    f32x4 acc[NT][WM][WN];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < WN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane fragment bases (bytes inside the dz / x image); rows add compile-time immediates
-    int a_lo[WT], a_hi[WT], b_lo[KW][WT], b_hi[KW][WT];
+    int a_lo[WM], a_hi[WM], b_lo[KW][WN], b_hi[KW][WN];
     {
         const int q = l15 >> 2, p = l15 & 3;
 #pragma unroll
-        for (int i = 0; i < WT; ++i) {
+        for (int i = 0; i < WM; ++i) {
             const int col = 8 * g + q, chb = (wco + 16 * i) * 2;
             a_lo[i] = col * REC + (chb ^ swz_bytes<REC>(col)) + 8 * p;
             a_hi[i] = (col + 4) * REC + (chb ^ swz_bytes<REC>(col + 4)) + 8 * p;
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
+            for (int j = 0; j < WN; ++j) {
                 const int col = kw + 8 * g + q, chb = (wci + 16 * j) * 2;
                 b_lo[kw][j] = C::DZ_BYTES + col * REC + (chb ^ swz_bytes<REC>(col)) + 8 * p;
                 b_hi[kw][j] = C::DZ_BYTES + (col + 4) * REC + (chb ^ swz_bytes<REC>(col + 4)) + 8 * p;
@@ -162,65 +161,61 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
 
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile) {
-        if (tile + 1 < t_end) issue(tile + 1, (cur ^ 1) * C::STAGE);
+        const bool more = tile + 1 < t_end;
         const char* img = smem + cur * C::STAGE;
-        // this wave group's half of the tile rows; K-step = one row of 32 pixels
+        auto load_a = [&](int r, uint4* fa) {
 #pragma unroll
-        for (int rr = 0; rr < TH / 2; ++rr) {
-            const int r = kg * (TH / 2) + rr;           // wave-uniform, folded into the base below
-            const char* ia = img + r * (32 * REC);
-            const char* ib = img + r * (SH * HWD * REC);
-            uint4 fa[WT];
+            for (int i = 0; i < WM; ++i) fa[i] = tr_frag2(img + r * (32 * REC) + a_lo[i], img + r * (32 * REC) + a_hi[i]);
+        };
+        auto load_b = [&](int r, int t2, uint4* fb) {
+            const int kh = t2 / KW, kw = t2 % KW;
 #pragma unroll
-            for (int i = 0; i < WT; ++i) fa[i] = tr_frag2(ia + a_lo[i], ia + a_hi[i]);
+            for (int j = 0; j < WN; ++j)
+                fb[j] = tr_frag2(img + (r * SH + kh) * (HWD * REC) + b_lo[kw][j], img + (r * SH + kh) * (HWD * REC) + b_hi[kw][j]);
+        };
+        // K-step = one tile row of 32 pixels.  Every fragment of row r+1 is requested before the MFMAs of
+        // row r (two register sets), so an LDS round trip is covered by a whole row of matrix work.
+        uint4 fa[2][WM], fb[2][NT][WN];
+        load_a(0, fa[0]);
 #pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2) {
-                const int kh = t2 / KW, kw = t2 % KW;
-                uint4 fb[WT];
+        for (int t2 = 0; t2 < NT; ++t2) load_b(0, t2, fb[0][t2]);
 #pragma unroll
-                for (int j = 0; j < WT; ++j)
-                    fb[j] = tr_frag2(ib + b_lo[kw][j] + kh * HWD * REC, ib + b_hi[kw][j] + kh * HWD * REC);
+        for (int r = 0; r < TH; ++r) {
+            if (r + 1 < TH) {
+                load_a(r + 1, fa[(r + 1) & 1]);
 #pragma unroll
-                for (int i = 0; i < WT; ++i)
-#pragma unroll
-                    for (int j = 0; j < WT; ++j)
-                        acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]), acc[t2][i][j], 0, 0, 0);
+                for (int t2 = 0; t2 < NT; ++t2) load_b(r + 1, t2, fb[(r + 1) & 1][t2]);
             }
+            // waves 0-3 and 4-7 issue the next tile's DMA one K-step apart, so on every SIMD one wave
+            // does address arithmetic while its partner feeds the matrix pipe
+            if (more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, fb[r & 1][t2][j]), acc[t2][i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
         __syncthreads();                                    // ... everyone's; and everyone is done reading `cur`
         cur ^= 1;
     }
 
-    // ---- sum the two wave groups through LDS: [acc4][wave4][lane] float4 ----
-    f32x4* red = (f32x4*)smem;
-    if (kg == 1) {
-#pragma unroll
-        for (int t2 = 0; t2 < NT; ++t2)
-#pragma unroll
-            for (int i = 0; i < WT; ++i)
-#pragma unroll
-                for (int j = 0; j < WT; ++j)
-                    red[(((t2 * WT + i) * WT + j) * 4 + w4) * 64 + lane] = acc[t2][i][j];
-    }
-    __syncthreads();
-    if (kg == 1) return;
-
     // ---- store the partial block: D[row = co = 4g+reg][col = ci = l15] ----
     float* slab = a.slab + (size_t)split * NT * a.Cout * a.Cin;
 #pragma unroll
     for (int t2 = 0; t2 < NT; ++t2)
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const f32x4 o = red[(((t2 * WT + i) * WT + j) * 4 + w4) * 64 + lane];
+            for (int j = 0; j < WN; ++j) {
                 const int ci = ci0 + wci + 16 * j + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wco + 16 * i + 4 * g + r;
-                    if (co < a.Cout && ci < a.Cin) slab[((size_t)t2 * a.Cout + co) * a.Cin + ci] = acc[t2][i][j][r] + o[r];
+                    if (co < a.Cout && ci < a.Cin) slab[((size_t)t2 * a.Cout + co) * a.Cin + ci] = acc[t2][i][j][r];
                 }
             }
 }
