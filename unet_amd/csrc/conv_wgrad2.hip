@@ -22,8 +22,19 @@
 
 __device__ __attribute__((aligned(64))) uint4 g_wgrad_zero[4];   // source of every padded 16-byte piece
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void glb_void;
+// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes
+// [lds_dst, lds_dst + 1024) in lane order (lds_dst wave-uniform).  Written as inline asm on purpose:
+// hipcc makes every later ds_read wait vmcnt(0) for a DMA it knows about, which would drain the
+// prefetch of the next tile at once; this way the kernel's own s_waitcnt before the tile barrier is
+// the only wait (no other vector-memory loads are in flight in the K loop).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
+}
 
 // REC = bytes per pixel record (128: 64 channels, 256: 128 channels).  XOR, in bytes, of the record's
 // 32-byte pieces: keeps the eight pieces that one 32-lane half of ds_read_b64_tr_b16 touches (pixel
@@ -109,6 +120,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     const __bf16* __restrict__ dzp = (const __bf16*)a.dz + a.dzoff + co0;
     const __bf16* __restrict__ xp = (const __bf16*)a.x + a.xoff + ci0;
     const char* zero = (const char*)g_wgrad_zero;
+    const unsigned smem_base = lds_addr(smem);
 
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
                     const int ho = h0 + r, wo = w0 + c;
                     const bool ok = ho < a.Hout && wo < a.Wout && (co0 + q * 8) < a.Cout;
                     const char* src = ok ? base + ((unsigned)((ho * a.Wout + wo) * a.lddz + q * 8) * 2u) : zero;
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem + stage_off + piece * 1024), 16, 0, 0);
+                    lds_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + stage_off + piece * 1024));
                 }
             }
         }
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
                     const int row = h0 * SH + hr - a.pad_h, col = w0 + hc - a.pad_w;
                     const bool ok = R < C::X_REC && row >= 0 && row < a.Hin && col >= 0 && col < a.Win && (ci0 + q * 8) < a.Cin;
                     const char* src = ok ? base + ((unsigned)((row * a.Win + col) * a.ldx + q * 8) * 2u) : zero;
-                    __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem + stage_off + C::DZ_BYTES + piece * 1024), 16, 0, 0);
+                    lds_dma16(src, __builtin_amdgcn_readfirstlane(smem_base + stage_off + C::DZ_BYTES + piece * 1024));
                 }
             }
         }
