@@ -75,9 +75,15 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4& acc, const uint4
 // which makes the 16-lane-group ds_read_b128 pattern (rows R..R+15, slot lane>>4) conflict-free.
 __device__ __forceinline__ int rec64_off(int R, int q) { return R * 64 + ((q ^ (((R >> 2) & 1) << 1)) << 4); }
 
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum16(float v) {
-    // sum over the 16 lanes that share lane>>4
-    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    // sum over the 16 lanes that share lane>>4 (one DPP row): quad swaps, then the two mirrors
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
     return v;
 }
 __device__ __forceinline__ float wave_sum64(float v) {

@@ -1,0 +1,293 @@
+// bf16 3x3 stride-1 implicit-GEMM convolution, second generation (gfx950): forward and dgrad of
+// nn.Conv2d(k=3,pad=1) (reference models/unet.py:10,13), same contract as conv_igemm.hip's 3x3 path
+// (bias, BN partial statistics, accumulate / ReLU flags, split destination).
+//
+// What changes against conv_igemm.hip is how operands reach the matrix cores:
+//   * persistent 512-thread workgroups, one per CU, walk output tiles of 16x32 pixels x BCO channels
+//     (BCO = 128: waves 2 (co) x 4 (row groups), 64 co x 128 px each; BCO = 64: 1 x 8, 64 co x 64 px).
+//   * a tile is a sequence of PHASES (32-channel chunk, kernel row kh): the phase's three taps of
+//     weights [3][BCO][32ch] and, once per chunk, the input halo tile [18][34][32ch] are written into
+//     LDS by global_load_lds_dwordx4 (no staging registers, no ds_write) while the previous phase is
+//     multiplied: two halo stages, two weight stages, one barrier per phase.  The pipeline runs across
+//     tile boundaries, so the next tile's first operands load under the epilogue.
+//   * zero padding (borders, ragged tiles, channel tails): the lane's SOURCE address points at a block
+//     of zeros; the LDS destination is lane-linear.
+//   * LDS images are 64-byte records (pixel or output channel x 32 input channels); the 16-byte slot is
+//     XOR-swizzled by a function of the pixel COLUMN / channel index, applied to the DMA source and to
+//     the ds_read_b128 fragment reads (conflict-free for every tap shift; rows add immediates).
+#include "common.h"
+#include "conv_args.h"
+#include "lds_dma.h"
+
+__device__ __attribute__((aligned(64))) uint4 g_conv_zero[4];
+
+template <int WC>
+struct Cv2Cfg {
+    static constexpr int BCO = 64 * WC;            // output channels per workgroup
+    static constexpr int NWR = 8 / WC;             // wave row groups
+    static constexpr int TH = 16, TW = 32;
+    static constexpr int RW = TH / NWR;            // tile rows per wave (4 or 2)
+    static constexpr int NPG = RW * 2;             // 16-pixel groups per wave
+    static constexpr int HP = 34;                  // halo row pitch (records)
+    static constexpr int HREC = (TH + 2) * HP;     // 612 records
+    static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
+    static constexpr int H_BYTES = H_PIECES * 1024;
+    static constexpr int W_PIECES = 3 * BCO / 16;  // one kernel row of taps
+    static constexpr int W_BYTES = W_PIECES * 1024;
+    static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
+    static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
+    static constexpr int SMEM = OFF_RED + RED_BYTES;
+    static_assert(SMEM <= 160 * 1024, "LDS budget");
+};
+
+__device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; }   // slot XOR of a 64-byte record
+
+template <int WC>
+__global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles) {
+    using C = Cv2Cfg<WC>;
+    constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP;
+
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned sb = lds_addr(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wc = (WC == 2) ? (wave >> 2) : 0;
+    const int wr = (WC == 2) ? (wave & 3) : wave;
+    const int nchunks = (a.Cin + 31) >> 5;
+
+    // ---- per-lane fragment bases ------------------------------------------------------------------
+    // A (weights): record = tapslot*BCO + wc*64 + ct*16 + l15, k-slot g
+    const int a_base = C::OFF_W + (wc * 64 + l15) * 64 + ((g ^ swz64(l15)) << 4);
+    // B (halo): record = (wr*RW + rr + kh)*HP + cc*16 + l15 + kw, k-slot g
+    int b_base[3][2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int col = cc * 16 + l15 + kw;
+            b_base[kw][cc] = C::OFF_H + ((wr * RW) * HP + col) * 64 + ((g ^ swz64(col)) << 4);
+        }
+
+    // ---- DMA addressing: recomputed from the lane id at every call (a dozen VALU per 1-KiB piece beside
+    // hundreds of MFMAs) so that no address plan has to live in registers across the K loop --------------
+    const char* zero = (const char*)g_conv_zero;
+    const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
+    const char* wg = (const char*)a.w;
+
+    struct Tile { int cb, n, h0, w0, pt; };
+    auto decode = [&](int t) {
+        Tile o;
+        o.cb = t % nco; o.pt = t / nco;
+        int p = o.pt;
+        const int tw_i = p % a.tiles_w; p /= a.tiles_w;
+        const int th_i = p % a.tiles_h;
+        o.n = p / a.tiles_h; o.h0 = th_i * C::TH; o.w0 = tw_i * C::TW;
+        return o;
+    };
+    // weights of one phase: taps kh*3 .. kh*3+2, channels [c*32, c*32+32) of output-channel block cb
+    auto issue_w = [&](const Tile& t, int c, int kh, int wstage) {
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));                          // opaque: nothing below is hoisted out of the loop
+        const int dl = lane_ >> 2, wq = (lane_ & 3) ^ swz64(lane_ >> 2);   // record in the piece, source chunk
+        const unsigned lw = (unsigned)(dl * a.Cin + wq * 8) * 2u;
+#pragma unroll
+        for (int i = 0; i < (C::W_PIECES + 7) / 8; ++i) {
+            const int p = wave + 8 * i;
+            if (p < C::W_PIECES) {
+                const int r0 = p * 16;
+                const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
+                const long long offu = ((long long)((kh * 3 + j) * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
+                const bool ok = (cou + dl) < a.Cout && (c * 32 + wq * 8) < a.Cin;
+                const char* src = ok ? wg + offu + lw : zero;
+                lds_dma16(src, __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
+            }
+        }
+    };
+    // input halo of one chunk: rows h0-pad .. +17, cols w0-pad .. +33, channels [c*32, c*32+32)
+    auto issue_h = [&](const Tile& t, int c, int hstage) {
+        const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
+        const long long offu = (((long long)t.n * a.Hin + r0) * a.Win + c0) * a.ldx * 2 + c * 64;          // wave-uniform
+        const char* xb = xg + offu;
+        int lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+        const int dl = lane_ >> 2, ds = lane_ & 3;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int r = (wave + 8 * i) * 16 + dl;
+            const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
+            const int q = ds ^ swz64(hc);
+            const int row = r0 + hr, col = c0 + hc, ci = c * 32 + q * 8;
+            const bool ok = r < C::HREC && (unsigned)row < (unsigned)a.Hin && (unsigned)col < (unsigned)a.Win && ci < a.Cin;
+            const unsigned lo = (unsigned)((hr * a.Win + hc) * a.ldx + q * 8) * 2u;
+            const char* src = ok ? xb + lo : zero;
+            lds_dma16(src, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + (wave + 8 * i) * 1024));
+        }
+    };
+
+    int tile_i = blockIdx.x;
+    if (tile_i >= total_tiles) return;
+    Tile cur = decode(tile_i);
+    issue_w(cur, 0, 0, 0);
+    issue_h(cur, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
+    for (;;) {
+        const int next_i = tile_i + gridDim.x;
+        const bool has_next = next_i < total_tiles;
+        const Tile nxt = decode(has_next ? next_i : tile_i);
+
+        f32x4 acc[4][NPG];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NPG; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < nchunks; ++c) {
+            const bool last_c = c + 1 == nchunks;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                // ---- prefetch: the next phase's weights; at kh == 0 the next chunk's halo -------------
+                if (kh < 2) issue_w(cur, c, kh + 1, ws ^ 1);
+                else if (!last_c) issue_w(cur, c + 1, 0, ws ^ 1);
+                else if (has_next) issue_w(nxt, 0, 0, ws ^ 1);
+                if (kh == 0) {
+                    if (!last_c) issue_h(cur, c + 1, hs ^ 1);
+                    else if (has_next) issue_h(nxt, 0, hs ^ 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // address temporaries die here, before the fragments go live
+                // ---- this phase: three taps -----------------------------------------------------------
+                const char* hb = smem + hs * C::H_BYTES;
+                const char* wb = smem + ws * C::W_BYTES;
+                // steps = (tap kw, pixel group pg): 4 MFMAs each.  B fragments run DEPTH steps ahead of
+                // their MFMAs in a small register ring; the next tap's A fragments are requested half a
+                // tap ahead.
+                constexpr int DEPTH = 3, RING = 4, NSTEP = 3 * NPG;
+                uint4 fa[2][4], fb[RING];
+                auto load_a = [&](int kw, uint4* fa_) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) fa_[ct] = *(const uint4*)(wb + a_base + kw * (BCO * 64) + ct * 1024);
+                };
+                auto load_b = [&](int step) {
+                    const int kw = step / NPG, pg = step % NPG;
+                    return *(const uint4*)(hb + b_base[kw][pg & 1] + ((pg >> 1) + kh) * (HP * 64));
+                };
+                load_a(0, fa[0]);
+#pragma unroll
+                for (int s0 = 0; s0 < DEPTH; ++s0) fb[s0 % RING] = load_b(s0);
+#pragma unroll
+                for (int st = 0; st < NSTEP; ++st) {
+                    const int kw = st / NPG, pg = st % NPG;
+                    if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
+                    if (pg == NPG / 2 && kw < 2) load_a(kw + 1, fa[(kw + 1) & 1]);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
+                __syncthreads();                                    // everyone's; and the stages just read are free
+                ws ^= 1;
+            }
+            hs ^= 1;
+        }
+
+        // ---- epilogue: + bias, per-channel sum / sum-of-squares partials, store -----------------------
+        const bool do_stats = a.stats != nullptr;
+        float* red = (float*)(smem + C::OFF_RED);     // [wr][BCO][2]
+        __bf16* __restrict__ yout = (__bf16*)a.y;
+        const int co_w = cur.cb * BCO + wc * 64;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int co = co_w + ct * 16 + 4 * g;
+            const bool co_ok = co < a.Cout;
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias != nullptr && co_ok) {
+                const float4 bv = *(const float4*)(a.bias + co);
+                b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+            }
+#pragma unroll
+            for (int pg = 0; pg < NPG; ++pg) {
+                const int ho = cur.h0 + wr * RW + (pg >> 1), wo = cur.w0 + (pg & 1) * 16 + l15;
+                const bool ok = co_ok && ho < a.Hout && wo < a.Wout;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[ct][pg][r] + b4[r];
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                    const size_t pix = ((size_t)cur.n * a.Hout + ho) * a.Wout + wo;
+                    __bf16* dst = yout + pix * a.ldy + a.yoff + co;
+                    if (a.csplit > 0 && co >= a.csplit) dst = (__bf16*)a.y2 + pix * a.ldy2 + a.yoff2 + (co - a.csplit);
+                    if (a.flags & 1) {
+                        const uint2 old = *(const uint2*)dst;
+                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                    }
+                    if (a.flags & 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    uint2 pk;
+                    pk.x = Vec16<__bf16>::pk(v[0], v[1]);
+                    pk.y = Vec16<__bf16>::pk(v[2], v[3]);
+                    *(uint2*)dst = pk;
+                }
+            }
+            if (do_stats) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t1 = wave_sum16(s1[r]);
+                    const float t2 = wave_sum16(s2[r]);
+                    if (l15 == 0) {
+                        red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 0] = t1;
+                        red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 1] = t2;
+                    }
+                }
+            }
+        }
+        if (do_stats) {
+            __syncthreads();
+            if (tid < BCO * 2) {
+                const int ch = tid >> 1, k = tid & 1;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < C::NWR; ++w) s += red[(w * BCO + ch) * 2 + k];
+                if (cur.cb * BCO + ch < a.Cout) a.stats[((size_t)cur.pt * a.Cout + cur.cb * BCO + ch) * 2 + k] = s;
+            }
+            __syncthreads();
+        }
+        if (!has_next) break;
+        tile_i = next_i;
+        cur = nxt;
+    }
+}
+
+template <int WC>
+static int launch_conv2(ConvArgs a, hipStream_t stream) {
+    using C = Cv2Cfg<WC>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
+        attr_done = true;
+    }
+    a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
+    const int nco = (a.Cout + C::BCO - 1) / C::BCO;
+    const int total = a.N * a.tiles_h * a.tiles_w * nco;
+    const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+// stat rows the bf16 3x3 path writes: one per 16x32 pixel tile
+int conv2_tiles(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wout + 31) / 32); }
+
+int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
+    return a.Cout > 64 ? launch_conv2<2>(a, s) : launch_conv2<1>(a, s);
+}

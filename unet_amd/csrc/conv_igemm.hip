@@ -15,20 +15,7 @@
 // global loads issued before the current stage's MFMAs (issue-early / write-late).
 #include "common.h"
 
-struct ConvArgs {
-    const void* x;
-    const void* w;
-    const float* bias;
-    void* y;
-    float* stats;
-    int N, Hin, Win, Cin, ldx, xoff;
-    int Hout, Wout, Cout, ldy, yoff;
-    int pad_h, pad_w, tiles_h, tiles_w;
-    // optional second destination: output channels >= csplit go to y2 at channel (co - csplit)
-    void* y2;
-    int ldy2, yoff2, csplit;
-    int flags;      // bit 0: y += conv (accumulate into the existing output), bit 1: ReLU on the result
-};
+#include "conv_args.h"
 
 template <typename T, int KH, int KW, int SH, int TG, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -262,6 +249,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// bf16 3x3 stride-1 path (conv_fwd2.hip)
+int conv2_tiles(int N, int Hout, int Wout);
+int dispatch_conv2(const ConvArgs& a, hipStream_t s);
+static bool use_conv2(int dtype, int kh, int kw, int sh, int epi) {
+    return dtype == UNET_BF16 && kh == 3 && kw == 3 && sh == 1 && epi == 0;
+}
+
 template <typename T>
 static int dispatch_conv(int kh, int kw, int sh, int epi, const ConvArgs& a, hipStream_t s) {
     if (epi == 1) {
@@ -284,7 +278,10 @@ static int dispatch_conv(int kh, int kw, int sh, int epi, const ConvArgs& a, hip
 }
 
 // stats_count() tells the caller how many partial rows unet_conv_fwd writes: one per pixel tile.
-extern "C" int unet_conv_tiles(int N, int Hout, int Wout) { return N * ((Hout + 7) / 8) * ((Wout + 31) / 32); }
+extern "C" int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout) {
+    if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_tiles(N, Hout, Wout);
+    return N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
+}
 
 extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                              const void* x, const void* w, const float* bias, void* y, float* stats,
@@ -313,6 +310,10 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     a.tiles_h = (Hout + 7) / 8; a.tiles_w = (Wout + 31) / 32;
     a.y2 = y2; a.ldy2 = ldy2; a.yoff2 = yoff2; a.csplit = csplit; a.flags = flags;
     hipStream_t s = (hipStream_t)stream;
+    if (use_conv2(dtype, kh, kw, stride_h, epi)) {
+        UNET_CHECK((size_t)9 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");
+        return dispatch_conv2(a, s);
+    }
     return dtype == UNET_BF16 ? dispatch_conv<__bf16>(kh, kw, stride_h, epi, a, s)
                               : dispatch_conv<float>(kh, kw, stride_h, epi, a, s);
 }

@@ -19,22 +19,9 @@
 //     same pixel range and share it through L2 / Infinity Cache.
 #include "common.h"
 #include "wgrad_args.h"
+#include "lds_dma.h"
 
 __device__ __attribute__((aligned(64))) uint4 g_wgrad_zero[4];   // source of every padded 16-byte piece
-
-// One LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes
-// [lds_dst, lds_dst + 1024) in lane order (lds_dst wave-uniform).  Written as inline asm on purpose:
-// hipcc makes every later ds_read wait vmcnt(0) for a DMA it knows about, which would drain the
-// prefetch of the next tile at once; this way the kernel's own s_waitcnt before the tile barrier is
-// the only wait (no other vector-memory loads are in flight in the K loop).
-__device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
-}
 
 // REC = bytes per pixel record (128: 64 channels, 256: 128 channels).  XOR, in bytes, of the record's
 // 32-byte pieces: keeps the eight pieces that one 32-lane half of ds_read_b64_tr_b16 touches (pixel

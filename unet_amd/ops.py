@@ -143,7 +143,7 @@ def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act
             raise UNetHipError("conv: bias must be fp32 of length Cout")
     rows = None
     if stats:
-        nrows = lib().unet_conv_tiles(x.N, Hout, Wout)
+        nrows = lib().unet_conv_tiles(dt, kh, kw, stride_h, epi, x.N, Hout, Wout)
         rows = torch.empty((nrows, Cout, 2), dtype=torch.float32, device=x.buf.device)
     check(lib().unet_conv_fwd(dt, kh, kw, stride_h, epi, _p(x.buf), _p(wpacked), _p(bias), _p(y.buf), _p(rows),
                               x.N, x.H, x.W, Cin, x.ld, x.off, Hout, Wout, Cout, y.ld, y.off, ph, pw,
