@@ -19,7 +19,6 @@
 #include "conv_args.h"
 #include "lds_dma.h"
 
-__device__ __attribute__((aligned(64))) uint4 g_conv_zero[4];
 
 template <int WC>
 struct Cv2Cfg {
@@ -32,7 +31,9 @@ struct Cv2Cfg {
     static constexpr int HREC = (TH + 2) * HP;     // 612 records
     static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
     static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int W_PIECES = 3 * BCO / 16;  // one kernel row of taps
+    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: a kernel row, or (64-channel tiles) the whole kernel
+    static constexpr int NPH = 9 / TPP;            // phases per 32-channel chunk
+    static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
     static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
@@ -45,7 +46,7 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 template <int WC>
 __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles) {
     using C = Cv2Cfg<WC>;
-    constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP;
+    constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned sb = lds_addr(smem);
@@ -70,9 +71,24 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             b_base[kw][cc] = C::OFF_H + ((wr * RW) * HP + col) * 64 + ((g ^ swz64(col)) << 4);
         }
 
-    // ---- DMA addressing: recomputed from the lane id at every call (a dozen VALU per 1-KiB piece beside
-    // hundreds of MFMAs) so that no address plan has to live in registers across the K loop --------------
-    const char* zero = (const char*)g_conv_zero;
+    // ---- DMA addressing ---------------------------------------------------------------------------
+    // Every piece is one buffer_load ... lds whose descriptor base is wave-uniform (tile origin, chunk,
+    // tap) and whose per-lane offset is a kernel-lifetime constant: hoff[i] for the lane's record/slot
+    // of halo piece wave+8i, woff for its row/slot of a 16-row weight piece.  A padded lane gets the
+    // out-of-range offset and the hardware writes zeros.  Per tile one bit mask says which of the
+    // lane's five halo pieces lie inside the image; channel counts that are not multiples of the tile
+    // (never in the U-Net) take the GENERIC path that recomputes everything per piece.
+    const int dl = lane >> 2, ds = lane & 3;       // record within the piece, 16-byte slot
+    const int wq = ds ^ swz64(dl);                 // weight source chunk (record index % 16 == dl)
+    const unsigned woff = (unsigned)(dl * a.Cin + wq * 8) * 2u;
+    unsigned hoff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int r = (wave + 8 * i) * 16 + dl;
+        const int hr = r / HP, hc = r - hr * HP;
+        hoff[i] = r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + (ds ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
+    }
+    const bool generic = (a.Cin & 31) != 0 || (a.Cout % BCO) != 0;
     const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
     const char* wg = (const char*)a.w;
 
@@ -86,51 +102,67 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         o.n = p / a.tiles_h; o.h0 = th_i * C::TH; o.w0 = tw_i * C::TW;
         return o;
     };
-    // weights of one phase: taps kh*3 .. kh*3+2, channels [c*32, c*32+32) of output-channel block cb
-    auto issue_w = [&](const Tile& t, int c, int kh, int wstage) {
+    // bit i: halo piece wave+8i of this lane lies inside the image for tile t
+    auto halo_mask = [&](const Tile& t) {
+        const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
+        unsigned m = 0;
+        if (r0 >= 0 && r0 + C::TH + 2 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return 0x1fu;     // interior tile (wave-uniform)
         int lane_ = lane;
-        asm volatile("" : "+v"(lane_));                          // opaque: nothing below is hoisted out of the loop
-        const int dl = lane_ >> 2, wq = (lane_ & 3) ^ swz64(lane_ >> 2);   // record in the piece, source chunk
-        const unsigned lw = (unsigned)(dl * a.Cin + wq * 8) * 2u;
+        asm volatile("" : "+v"(lane_));
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int r = (wave + 8 * i) * 16 + (lane_ >> 2);
+            const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
+            if ((unsigned)(r0 + hr) < (unsigned)a.Hin && (unsigned)(c0 + hc) < (unsigned)a.Win) m |= 1u << i;
+        }
+        return m;
+    };
+    // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
+    auto issue_w = [&](const Tile& t, int c, int ph, int wstage) {
 #pragma unroll
         for (int i = 0; i < (C::W_PIECES + 7) / 8; ++i) {
             const int p = wave + 8 * i;
             if (p < C::W_PIECES) {
                 const int r0 = p * 16;
                 const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
-                const long long offu = ((long long)((kh * 3 + j) * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
-                const bool ok = (cou + dl) < a.Cout && (c * 32 + wq * 8) < a.Cin;
-                const char* src = ok ? wg + offu + lw : zero;
-                lds_dma16(src, __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
+                const long long offu = ((long long)((ph * TPP + j) * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
+                unsigned v = woff;
+                if (generic) {
+                    int lane_ = lane;
+                    asm volatile("" : "+v"(lane_));
+                    const int dl_ = lane_ >> 2, wq_ = (lane_ & 3) ^ swz64(dl_);
+                    v = ((cou + dl_) < a.Cout && (c * 32 + wq_ * 8) < a.Cin) ? woff : LDS_DMA_OOB;
+                }
+                lds_dma16_buf(make_rsrc(wg + offu, LDS_DMA_RECORDS), v,
+                              __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
             }
         }
     };
     // input halo of one chunk: rows h0-pad .. +17, cols w0-pad .. +33, channels [c*32, c*32+32)
-    auto issue_h = [&](const Tile& t, int c, int hstage) {
+    auto issue_h = [&](const Tile& t, int c, int hstage, unsigned mask) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         const long long offu = (((long long)t.n * a.Hin + r0) * a.Win + c0) * a.ldx * 2 + c * 64;          // wave-uniform
-        const char* xb = xg + offu;
-        int lane_ = lane;
-        asm volatile("" : "+v"(lane_));
-        const int dl = lane_ >> 2, ds = lane_ & 3;
+        const i32x4_t rsrc = make_rsrc(xg + offu, LDS_DMA_RECORDS);
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
-            const int r = (wave + 8 * i) * 16 + dl;
-            const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
-            const int q = ds ^ swz64(hc);
-            const int row = r0 + hr, col = c0 + hc, ci = c * 32 + q * 8;
-            const bool ok = r < C::HREC && (unsigned)row < (unsigned)a.Hin && (unsigned)col < (unsigned)a.Win && ci < a.Cin;
-            const unsigned lo = (unsigned)((hr * a.Win + hc) * a.ldx + q * 8) * 2u;
-            const char* src = ok ? xb + lo : zero;
-            lds_dma16(src, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + (wave + 8 * i) * 1024));
+            unsigned v = ((mask >> i) & 1u) ? hoff[i] : LDS_DMA_OOB;
+            if (generic) {
+                int lane_ = lane;
+                asm volatile("" : "+v"(lane_));
+                const int r = (wave + 8 * i) * 16 + (lane_ >> 2);
+                const int hr = (r * 241) >> 13, hc = r - hr * HP;
+                if (c * 32 + ((lane_ & 3) ^ swz64(hc)) * 8 >= a.Cin) v = LDS_DMA_OOB;
+            }
+            lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + (wave + 8 * i) * 1024));
         }
     };
 
     int tile_i = blockIdx.x;
     if (tile_i >= total_tiles) return;
     Tile cur = decode(tile_i);
+    unsigned mask_cur = halo_mask(cur);
     issue_w(cur, 0, 0, 0);
-    issue_h(cur, 0, 0);
+    issue_h(cur, 0, 0, mask_cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -139,6 +171,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const int next_i = tile_i + gridDim.x;
         const bool has_next = next_i < total_tiles;
         const Tile nxt = decode(has_next ? next_i : tile_i);
+        unsigned mask_nxt = mask_cur;
 
         f32x4 acc[4][NPG];
 #pragma unroll
@@ -149,40 +182,40 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         for (int c = 0; c < nchunks; ++c) {
             const bool last_c = c + 1 == nchunks;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                // ---- prefetch: the next phase's weights; at kh == 0 the next chunk's halo -------------
-                if (kh < 2) issue_w(cur, c, kh + 1, ws ^ 1);
+            for (int ph = 0; ph < NPH; ++ph) {
+                // ---- prefetch: the next phase's weights; at ph == 0 the next chunk's halo -------------
+                if (ph + 1 < NPH) issue_w(cur, c, ph + 1, ws ^ 1);
                 else if (!last_c) issue_w(cur, c + 1, 0, ws ^ 1);
                 else if (has_next) issue_w(nxt, 0, 0, ws ^ 1);
-                if (kh == 0) {
-                    if (!last_c) issue_h(cur, c + 1, hs ^ 1);
-                    else if (has_next) issue_h(nxt, 0, hs ^ 1);
+                if (ph == 0) {
+                    if (!last_c) issue_h(cur, c + 1, hs ^ 1, mask_cur);
+                    else if (has_next) { mask_nxt = halo_mask(nxt); issue_h(nxt, 0, hs ^ 1, mask_nxt); }
                 }
                 __builtin_amdgcn_sched_barrier(0);     // address temporaries die here, before the fragments go live
-                // ---- this phase: three taps -----------------------------------------------------------
+                // ---- this phase: TPP taps -----------------------------------------------------------
                 const char* hb = smem + hs * C::H_BYTES;
                 const char* wb = smem + ws * C::W_BYTES;
-                // steps = (tap kw, pixel group pg): 4 MFMAs each.  B fragments run DEPTH steps ahead of
+                // steps = (tap j, pixel group pg): 4 MFMAs each.  B fragments run DEPTH steps ahead of
                 // their MFMAs in a small register ring; the next tap's A fragments are requested half a
                 // tap ahead.
-                constexpr int DEPTH = 3, RING = 4, NSTEP = 3 * NPG;
+                constexpr int DEPTH = 3, RING = 4, NSTEP = TPP * NPG;
                 uint4 fa[2][4], fb[RING];
-                auto load_a = [&](int kw, uint4* fa_) {
+                auto load_a = [&](int j, uint4* fa_) {
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) fa_[ct] = *(const uint4*)(wb + a_base + kw * (BCO * 64) + ct * 1024);
+                    for (int ct = 0; ct < 4; ++ct) fa_[ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
                 };
                 auto load_b = [&](int step) {
-                    const int kw = step / NPG, pg = step % NPG;
-                    return *(const uint4*)(hb + b_base[kw][pg & 1] + ((pg >> 1) + kh) * (HP * 64));
+                    const int tap = ph * TPP + step / NPG, pg = step % NPG;
+                    return *(const uint4*)(hb + b_base[tap % 3][pg & 1] + ((pg >> 1) + tap / 3) * (HP * 64));
                 };
                 load_a(0, fa[0]);
 #pragma unroll
                 for (int s0 = 0; s0 < DEPTH; ++s0) fb[s0 % RING] = load_b(s0);
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
-                    const int kw = st / NPG, pg = st % NPG;
+                    const int kw = st / NPG, pg = st % NPG;      // kw: tap slot inside the phase
                     if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
-                    if (pg == NPG / 2 && kw < 2) load_a(kw + 1, fa[(kw + 1) & 1]);
+                    if (pg == NPG / 2 && kw + 1 < TPP) load_a(kw + 1, fa[(kw + 1) & 1]);
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct)
                         acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         if (!has_next) break;
         tile_i = next_i;
         cur = nxt;
+        mask_cur = mask_nxt;
     }
 }
 

@@ -16,3 +16,25 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)p;
 }
+
+// The same through a buffer descriptor: 64 lanes x 16 bytes from rsrc.base + voff (per lane) to LDS.
+// A lane whose voff is >= rsrc.num_records reads nothing and writes ZEROS: that is how image borders,
+// ragged tiles and channel tails are padded without a per-lane pointer select.  The leading s_nop
+// covers the SALU-write -> VMEM-descriptor-read hazard that hipcc cannot see inside the statement.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t make_rsrc(const void* base, unsigned num_records) {
+    const unsigned long long p = (unsigned long long)base;
+    i32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)p);
+    r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(p >> 32) & 0xffffu));
+    r.z = (int)num_records;
+    r.w = 0x00020000;
+    return r;
+}
+#define LDS_DMA_OOB 0xFFFFFFF0u          /* voff of a padded lane */
+#define LDS_DMA_RECORDS 0xFFFFFF00u      /* num_records of descriptors whose base is a tile origin */
+__device__ __forceinline__ void lds_dma16_buf(i32x4_t rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
