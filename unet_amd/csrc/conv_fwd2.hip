@@ -18,6 +18,7 @@
 #include "common.h"
 #include "conv_args.h"
 #include "lds_dma.h"
+#include <type_traits>
 
 
 template <int WC>
@@ -231,58 +232,81 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         // ---- epilogue: + bias, per-channel sum / sum-of-squares partials, store -----------------------
         const bool do_stats = a.stats != nullptr;
         float* red = (float*)(smem + C::OFF_RED);     // [wr][BCO][2]
-        __bf16* __restrict__ yout = (__bf16*)a.y;
         const int co_w = cur.cb * BCO + wc * 64;
+        // FAST: the tile lies inside the output, plain store (no accumulate / ReLU), and this wave's 64
+        // channels go to one destination: every store is a wave-uniform base plus one per-lane offset
+        const bool fast = cur.h0 + C::TH <= a.Hout && cur.w0 + C::TW <= a.Wout && co_w + 64 <= a.Cout &&
+                          (a.flags & 3) == 0 && (a.csplit & 63) == 0;
+        auto epilogue = [&](auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const bool second = a.csplit > 0 && co_w >= a.csplit;                       // wave-uniform when FAST
+            char* ydst = second ? (char*)a.y2 : (char*)a.y;
+            const int ld = second ? a.ldy2 : a.ldy;
+            const int chan0 = second ? a.yoff2 + co_w - a.csplit : a.yoff + co_w;
+            const size_t pix0 = ((size_t)cur.n * a.Hout + cur.h0 + wr * RW) * a.Wout + cur.w0;
+            char* ybase = ydst + (pix0 * ld + chan0) * 2;                                // wave-uniform
+            const unsigned lane_off = (unsigned)(l15 * ld + 4 * g) * 2u;
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const int co = co_w + ct * 16 + 4 * g;
-            const bool co_ok = co < a.Cout;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias != nullptr && co_ok) {
-                const float4 bv = *(const float4*)(a.bias + co);
-                b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
-            }
+            for (int ct = 0; ct < 4; ++ct) {
+                const int co = co_w + ct * 16 + 4 * g;
+                const bool co_ok = FAST || co < a.Cout;
+                float b4[4] = {0.f, 0.f, 0.f, 0.f};
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias != nullptr && co_ok) {
+                    const float4 bv = *(const float4*)(a.bias + co);
+                    b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+                }
 #pragma unroll
-            for (int pg = 0; pg < NPG; ++pg) {
-                const int ho = cur.h0 + wr * RW + (pg >> 1), wo = cur.w0 + (pg & 1) * 16 + l15;
-                const bool ok = co_ok && ho < a.Hout && wo < a.Wout;
-                float v[4];
+                for (int pg = 0; pg < NPG; ++pg) {
+                    float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[ct][pg][r] + b4[r];
-                if (ok) {
+                    for (int r = 0; r < 4; ++r) v[r] = acc[ct][pg][r] + b4[r];
+                    if constexpr (FAST) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-                    const size_t pix = ((size_t)cur.n * a.Hout + ho) * a.Wout + wo;
-                    __bf16* dst = yout + pix * a.ldy + a.yoff + co;
-                    if (a.csplit > 0 && co >= a.csplit) dst = (__bf16*)a.y2 + pix * a.ldy2 + a.yoff2 + (co - a.csplit);
-                    if (a.flags & 1) {
-                        const uint2 old = *(const uint2*)dst;
-                        v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-                        v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                        uint2 pk;
+                        pk.x = Vec16<__bf16>::pk(v[0], v[1]);
+                        pk.y = Vec16<__bf16>::pk(v[2], v[3]);
+                        char* bu = ybase + ((size_t)((pg >> 1) * a.Wout + (pg & 1) * 16) * ld + ct * 16) * 2;   // wave-uniform
+                        *(uint2*)(bu + lane_off) = pk;
+                    } else {
+                        const int ho = cur.h0 + wr * RW + (pg >> 1), wo = cur.w0 + (pg & 1) * 16 + l15;
+                        if (co_ok && ho < a.Hout && wo < a.Wout) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
+                            const size_t pix = ((size_t)cur.n * a.Hout + ho) * a.Wout + wo;
+                            __bf16* dst = (__bf16*)a.y + pix * a.ldy + a.yoff + co;
+                            if (a.csplit > 0 && co >= a.csplit) dst = (__bf16*)a.y2 + pix * a.ldy2 + a.yoff2 + (co - a.csplit);
+                            if (a.flags & 1) {
+                                const uint2 old = *(const uint2*)dst;
+                                v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+                                v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+                            }
+                            if (a.flags & 2) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                            }
+                            uint2 pk;
+                            pk.x = Vec16<__bf16>::pk(v[0], v[1]);
+                            pk.y = Vec16<__bf16>::pk(v[2], v[3]);
+                            *(uint2*)dst = pk;
+                        }
                     }
-                    if (a.flags & 2) {
+                }
+                if (do_stats) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) {
+                        const float t1 = wave_sum16(s1[r]);
+                        const float t2 = wave_sum16(s2[r]);
+                        if (l15 == 0) {
+                            red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 0] = t1;
+                            red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 1] = t2;
+                        }
                     }
-                    uint2 pk;
-                    pk.x = Vec16<__bf16>::pk(v[0], v[1]);
-                    pk.y = Vec16<__bf16>::pk(v[2], v[3]);
-                    *(uint2*)dst = pk;
                 }
             }
-            if (do_stats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float t1 = wave_sum16(s1[r]);
-                    const float t2 = wave_sum16(s2[r]);
-                    if (l15 == 0) {
-                        red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 0] = t1;
-                        red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 1] = t2;
-                    }
-                }
-            }
-        }
+        };
+        if (fast) epilogue(std::true_type{}); else epilogue(std::false_type{});
         if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
