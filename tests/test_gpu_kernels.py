@@ -78,6 +78,10 @@ CONV_SHAPES = [
     (2, 20, 20, 40, 72),
     (1, 4, 4, 128, 136),
     (3, 9, 33, 8, 8),
+    # whole 16x32 tiles and channel multiples of the block: the specialised bf16 3x3 kernels
+    (1, 16, 32, 64, 64),
+    (2, 32, 64, 32, 128),
+    (1, 48, 32, 128, 256),
 ]
 KERNELS = [(3, 3), (1, 1), (5, 5), (3, 1), (1, 3), (5, 1), (1, 5)]
 
@@ -130,17 +134,18 @@ def test_conv_fwd_dgrad_wgrad(dev, dt, k, shape):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-def test_conv_split_output(dev, dt):
+@pytest.mark.parametrize("geom", [(2, 12, 36, 32, 48, 16), (1, 32, 32, 64, 192, 64), (1, 16, 64, 32, 128, 64)])
+def test_conv_split_output(dev, dt, geom):
     ops = ops_mod()
-    N, H, W, Cin, Cout = 2, 12, 36, 32, 48
+    N, H, W, Cin, Cout, cs = geom
     x = q(rnd((N, Cin, H, W), 5), dt)
     w = q(rnd((Cout, Cin, 3, 3), 6, 0.1), dt)
     ref = F.conv2d(x, w, None, padding=1)
     xa = to_act(x, dt, dev)
-    y1, y2 = ops.dense(N, H, W, 16, dt, dev), ops.dense(N, H, W, 32, dt, dev)
-    ops.conv_fwd(xa, ops.pack_weights(w.to(dev), 0, dt), None, y1, 3, 3, Cin, Cout, y2=y2, csplit=16)
-    close(from_act(y1), ref[:, :16], dt, "split lo")
-    close(from_act(y2), ref[:, 16:], dt, "split hi")
+    y1, y2 = ops.dense(N, H, W, cs, dt, dev), ops.dense(N, H, W, Cout - cs, dt, dev)
+    ops.conv_fwd(xa, ops.pack_weights(w.to(dev), 0, dt), None, y1, 3, 3, Cin, Cout, y2=y2, csplit=cs)
+    close(from_act(y1), ref[:, :cs], dt, "split lo")
+    close(from_act(y2), ref[:, cs:], dt, "split hi")
 
 
 @pytest.mark.parametrize("dt", [0, 1])

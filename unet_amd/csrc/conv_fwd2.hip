@@ -44,7 +44,10 @@ struct Cv2Cfg {
 
 __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; }   // slot XOR of a 64-byte record
 
-template <int WC>
+// GEN = false: the specialised kernel of the U-Net shapes (channel counts multiples of the tile, output
+// a whole number of 16x32 tiles, plain store, split point on a 64-channel boundary); GEN = true: the
+// same pipeline with every bound checked per lane and the accumulate / ReLU / arbitrary-split stores.
+template <int WC, bool GEN>
 __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles) {
     using C = Cv2Cfg<WC>;
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const int hr = r / HP, hc = r - hr * HP;
         hoff[i] = r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + (ds ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
     }
-    const bool generic = (a.Cin & 31) != 0 || (a.Cout % BCO) != 0;
+    constexpr bool generic = GEN;
     const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
     const char* wg = (const char*)a.w;
 
@@ -235,8 +238,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const int co_w = cur.cb * BCO + wc * 64;
         // FAST: the tile lies inside the output, plain store (no accumulate / ReLU), and this wave's 64
         // channels go to one destination: every store is a wave-uniform base plus one per-lane offset
-        const bool fast = cur.h0 + C::TH <= a.Hout && cur.w0 + C::TW <= a.Wout && co_w + 64 <= a.Cout &&
-                          (a.flags & 3) == 0 && (a.csplit & 63) == 0;
+        constexpr bool fast = !GEN;
         auto epilogue = [&](auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
             const bool second = a.csplit > 0 && co_w >= a.csplit;                       // wave-uniform when FAST
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 }
             }
         };
-        if (fast) epilogue(std::true_type{}); else epilogue(std::false_type{});
+        epilogue(std::integral_constant<bool, fast>{});
         if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
@@ -325,12 +327,12 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     }
 }
 
-template <int WC>
+template <int WC, bool GEN>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
@@ -338,7 +340,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total);
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total);
     UNET_LAUNCH_CHECK();
     return 0;
 }
@@ -347,5 +349,9 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
 int conv2_tiles(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wout + 31) / 32); }
 
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
-    return a.Cout > 64 ? launch_conv2<2>(a, s) : launch_conv2<1>(a, s);
+    const int bco = a.Cout > 64 ? 128 : 64;
+    const bool gen = (a.Cin & 31) != 0 || (a.Cout % bco) != 0 || (a.Hout & 15) != 0 || (a.Wout & 31) != 0 ||
+                     (a.flags & 3) != 0 || (a.csplit & 63) != 0;
+    if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
+    return gen ? launch_conv2<1, true>(a, s) : launch_conv2<1, false>(a, s);
 }
