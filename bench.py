@@ -175,7 +175,7 @@ def main():
             ach = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                               "kernel": "conv_igemm_kernel<bf16,3,3,1,9,0> (3x3 fwd + dgrad launches)",
+                               "kernel": "conv3x3_v2_kernel<WC,GEN> (bf16 3x3 fwd + dgrad launches)",
                                "launches": n, "avg_launch_ms": ms / n, "avg_launch_gflop": fl / n / 1e9}
             out["train_step_tflops"] = TRAIN_GFLOP_PER_IMAGE_512 * (args.size / 512.0) ** 2 * value / 1e3
         if world == 1 and not args.no_cpu_baseline:

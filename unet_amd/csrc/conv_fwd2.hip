@@ -38,7 +38,8 @@ struct Cv2Cfg {
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
     static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
-    static constexpr int SMEM = OFF_RED + RED_BYTES;
+    static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
+    static constexpr int SMEM = OFF_BIAS + 2 * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
@@ -122,7 +123,13 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         return m;
     };
     // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
-    auto issue_w = [&](const Tile& t, int c, int ph, int wstage) {
+    auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot) {
+        if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) {
+            // the tile's biases ride with its first weights (wave 0, one piece; lanes past the block read zeros)
+            const int nb = min(BCO, a.Cout - t.cb * BCO) * 4;
+            lds_dma16_buf(make_rsrc(a.bias + t.cb * BCO, (unsigned)nb), (unsigned)lane * 16u,
+                          __builtin_amdgcn_readfirstlane(sb + C::OFF_BIAS + bslot * 1024));
+        }
 #pragma unroll
         for (int i = 0; i < (C::W_PIECES + 7) / 8; ++i) {
             const int p = wave + 8 * i;
@@ -161,22 +168,49 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         }
     };
 
-    int tile_i = blockIdx.x;
-    if (tile_i >= total_tiles) return;
-    Tile cur = decode(tile_i);
-    unsigned mask_cur = halo_mask(cur);
-    issue_w(cur, 0, 0, 0);
-    issue_h(cur, 0, 0, mask_cur);
+    // ---- issue-side cursors: the next weight phase and the next halo chunk to request ------------------
+    struct Cursor { int tile_i, c, ph, seq; Tile t; bool valid; };
+    auto cursor_at = [&](int tile_i) {
+        Cursor q;
+        q.tile_i = tile_i; q.c = 0; q.ph = 0; q.seq = 0;
+        q.valid = tile_i < total_tiles;
+        q.t = decode(q.valid ? tile_i : 0);
+        return q;
+    };
+    auto next_tile = [&](Cursor& q) {
+        q.c = 0; q.tile_i += gridDim.x; q.seq ^= 1;
+        q.valid = q.tile_i < total_tiles;
+        if (q.valid) q.t = decode(q.tile_i);
+    };
+    if ((int)blockIdx.x >= total_tiles) return;
+    Cursor wq_ = cursor_at(blockIdx.x);        // weights: advances phase by phase
+    Cursor hq_ = wq_;                          // halo: advances chunk by chunk
+    unsigned hmask = halo_mask(hq_.t);
+    int wstage_i = 0, hstage_i = 0;
+    auto push_w = [&]() {
+        if (!wq_.valid) return;
+        issue_w(wq_.t, wq_.c, wq_.ph, wstage_i, wq_.seq);
+        wstage_i ^= 1;
+        if (++wq_.ph == NPH) { wq_.ph = 0; if (++wq_.c == nchunks) next_tile(wq_); }
+    };
+    auto push_h = [&]() {
+        if (!hq_.valid) return false;
+        issue_h(hq_.t, hq_.c, hstage_i, hmask);
+        hstage_i ^= 1;
+        if (++hq_.c == nchunks) { next_tile(hq_); if (hq_.valid) hmask = halo_mask(hq_.t); }
+        return true;
+    };
+    // prologue: phases 0 and 1 (and, for one-phase chunks, halo chunks 0 and 1)
+    push_w(); push_h(); push_w();
+    if (NPH == 1) push_h();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int tile_i = blockIdx.x, tseq = 0;
+    Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
+    bool h_flying = false;     // a halo request that the next wait may leave in flight
     for (;;) {
-        const int next_i = tile_i + gridDim.x;
-        const bool has_next = next_i < total_tiles;
-        const Tile nxt = decode(has_next ? next_i : tile_i);
-        unsigned mask_nxt = mask_cur;
-
         f32x4 acc[4][NPG];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -184,18 +218,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             for (int j = 0; j < NPG; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int c = 0; c < nchunks; ++c) {
-            const bool last_c = c + 1 == nchunks;
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
-                // ---- prefetch: the next phase's weights; at ph == 0 the next chunk's halo -------------
-                if (ph + 1 < NPH) issue_w(cur, c, ph + 1, ws ^ 1);
-                else if (!last_c) issue_w(cur, c + 1, 0, ws ^ 1);
-                else if (has_next) issue_w(nxt, 0, 0, ws ^ 1);
-                if (ph == 0) {
-                    if (!last_c) issue_h(cur, c + 1, hs ^ 1, mask_cur);
-                    else if (has_next) { mask_nxt = halo_mask(nxt); issue_h(nxt, 0, hs ^ 1, mask_nxt); }
-                }
-                __builtin_amdgcn_sched_barrier(0);     // address temporaries die here, before the fragments go live
                 // ---- this phase: TPP taps -----------------------------------------------------------
                 const char* hb = smem + hs * C::H_BYTES;
                 const char* wb = smem + ws * C::W_BYTES;
@@ -225,8 +249,16 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                         acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
-                __syncthreads();                                    // everyone's; and the stages just read are free
+                // ---- the next phase's operands have landed: a halo requested one phase ago (its five
+                // pieces are this wave's youngest requests) may stay in flight for one more phase -----
+                if (NPH == 3 && ph == 1 && h_flying) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                h_flying = false;
+                __syncthreads();                        // everyone's pieces; and the stages just read are free
+                // ---- refill what was just freed: weights two phases ahead, then the halo -----------------
+                push_w();
+                if (NPH == 1) push_h();
+                else if (ph == 0) h_flying = push_h();
                 ws ^= 1;
             }
             hs ^= 1;
@@ -254,8 +286,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 const bool co_ok = FAST || co < a.Cout;
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias != nullptr && co_ok) {
-                    const float4 bv = *(const float4*)(a.bias + co);
+                if (a.bias != nullptr) {        // staged in LDS with the tile's first weights (zeros past Cout)
+                    const float4 bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
                     b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
                 }
 #pragma unroll
@@ -320,10 +352,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             }
             __syncthreads();
         }
-        if (!has_next) break;
-        tile_i = next_i;
-        cur = nxt;
-        mask_cur = mask_nxt;
+        tile_i += gridDim.x; tseq ^= 1;
+        if (tile_i >= total_tiles) break;
+        cur = decode(tile_i);
     }
 }
 
