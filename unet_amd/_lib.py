@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunet_hip.so")
+LIB_PATH = os.environ.get("UNET_HIP_LIB") or os.path.join(_HERE, "libunet_hip.so")   # override: diagnostic builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "unet_hip.h")
 
 _lib = None

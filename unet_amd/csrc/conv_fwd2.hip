@@ -43,13 +43,22 @@ struct Cv2Cfg {
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
+#ifdef CV2_TRACE
+// diagnostic build only (make TRACE=1): s_memtime stamps of block 0, waves 0 and 4
+__device__ unsigned long long* g_cv2_trace = nullptr;
+extern "C" int unet_debug_set_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cv2_trace), &p, sizeof(p)); }
+#define STAMP(tag) do { if (trc && tn < 500) { trc[tn * 2] = __builtin_amdgcn_s_memtime(); trc[tn * 2 + 1] = (tag); ++tn; } } while (0)
+#else
+#define STAMP(tag) do { } while (0)
+#endif
+
 __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; }   // slot XOR of a 64-byte record
 
 // GEN = false: the specialised kernel of the U-Net shapes (channel counts multiples of the tile, output
 // a whole number of 16x32 tiles, plain store, split point on a 64-channel boundary); GEN = true: the
 // same pipeline with every bound checked per lane and the accumulate / ReLU / arbitrary-split stores.
 template <int WC, bool GEN>
-__global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles) {
+__global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC>;
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
@@ -62,6 +71,10 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     const int wc = (WC == 2) ? (wave >> 2) : 0;
     const int wr = (WC == 2) ? (wave & 3) : wave;
     const int nchunks = (a.Cin + 31) >> 5;
+#ifdef CV2_TRACE
+    unsigned long long* trc = (g_cv2_trace && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ? g_cv2_trace + (wave >> 2) * 1024 : nullptr;
+    int tn = 0;
+#endif
 
     // ---- per-lane fragment bases ------------------------------------------------------------------
     // A (weights): record = tapslot*BCO + wc*64 + ct*16 + l15, k-slot g
@@ -100,11 +113,11 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     struct Tile { int cb, n, h0, w0, pt; };
     auto decode = [&](int t) {
         Tile o;
-        o.cb = t % nco; o.pt = t / nco;
-        int p = o.pt;
-        const int tw_i = p % a.tiles_w; p /= a.tiles_w;
-        const int th_i = p % a.tiles_h;
-        o.n = p / a.tiles_h; o.h0 = th_i * C::TH; o.w0 = tw_i * C::TW;
+        o.pt = (int)fdiv((unsigned)t, d_nco); o.cb = t - o.pt * nco;
+        const int p1 = (int)fdiv((unsigned)o.pt, d_tw), tw_i = o.pt - p1 * a.tiles_w;
+        o.n = (int)fdiv((unsigned)p1, d_th);
+        const int th_i = p1 - o.n * a.tiles_h;
+        o.h0 = th_i * C::TH; o.w0 = tw_i * C::TW;
         return o;
     };
     // bit i: halo piece wave+8i of this lane lies inside the image for tile t
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
+                STAMP(1);
                 // ---- this phase: TPP taps -----------------------------------------------------------
                 const char* hb = smem + hs * C::H_BYTES;
                 const char* wb = smem + ws * C::W_BYTES;
@@ -251,15 +265,19 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 }
                 // ---- the next phase's operands have landed: a halo requested one phase ago (its five
                 // pieces are this wave's youngest requests) may stay in flight for one more phase -----
+                STAMP(2);
                 if (NPH == 3 && ph == 1 && h_flying) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 h_flying = false;
+                STAMP(3);
                 __syncthreads();                        // everyone's pieces; and the stages just read are free
+                STAMP(4);
                 // ---- refill what was just freed: weights two phases ahead, then the halo -----------------
                 push_w();
                 if (NPH == 1) push_h();
                 else if (ph == 0) h_flying = push_h();
                 ws ^= 1;
+                STAMP(5);
             }
             hs ^= 1;
         }
@@ -352,6 +370,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             }
             __syncthreads();
         }
+        STAMP(6);
         tile_i += gridDim.x; tseq ^= 1;
         if (tile_i >= total_tiles) break;
         cur = decode(tile_i);
@@ -371,7 +390,10 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total);
+    UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
+               "tile count too large for the index arithmetic");
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total,
+                       make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
 }

@@ -60,7 +60,7 @@ struct Wg2Cfg {
 };
 
 template <int KH, int KW, int SH, int WT, int TH>
-__global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan) {
+__global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan, FastDiv d_tw, FastDiv d_th) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     constexpr int REC = C::REC, SLOTS = C::SLOTS, RPP = C::RPP, HWD = C::HWD, NT = C::NT, CT = C::CT;
 
@@ -114,10 +114,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
 
     // One tile's DMA: every wave issues its share of the 1-KiB pieces of both images.
     auto issue = [&](int tile, int stage_off) {
-        int t = tile;
-        const int tw_i = t % a.tiles_w; t /= a.tiles_w;
-        const int th_i = t % a.tiles_h;
-        const int n = t / a.tiles_h;
+        const int p1 = (int)fdiv((unsigned)tile, d_tw), tw_i = tile - p1 * a.tiles_w;
+        const int n = (int)fdiv((unsigned)p1, d_th), th_i = p1 - n * a.tiles_h;
         const int h0 = th_i * TH, w0 = tw_i * C::TW;
         const int rl = lane / SLOTS, s = lane % SLOTS;
         {
@@ -233,8 +231,10 @@ static int launch_wgrad2(WgradArgs a, hipStream_t stream, int nsplit) {
     a.tiles_total = a.N * a.tiles_h * a.tiles_w;
     a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
     const int nco = (a.Cout + C::CT - 1) / C::CT, nci = (a.Cin + C::CT - 1) / C::CT;
+    UNET_CHECK((unsigned long long)a.tiles_total * (unsigned)(a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h) < (1ull << 32),
+               "tile count too large for the index arithmetic");
     hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH>), dim3((unsigned)(nsplit * nco * nci)), dim3(512), C::SMEM, stream,
-                       a, nci, nco * nci);
+                       a, nci, nco * nci, make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
 }

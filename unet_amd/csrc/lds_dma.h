@@ -38,3 +38,14 @@ __device__ __forceinline__ void lds_dma16_buf(i32x4_t rsrc, unsigned voff, unsig
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
+
+// Division of small wave-uniform unsigned numbers by a launch constant without the float sequence hipcc
+// emits for a runtime divisor: q = mulhi(x, ceil(2^32 / d)), exact while x * d < 2^32 (the launchers
+// check); d == 1 is encoded as magic 0.
+struct FastDiv { unsigned d, magic; };
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f; f.d = d;
+    f.magic = d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return f.magic ? __umulhi(x, f.magic) : x; }
