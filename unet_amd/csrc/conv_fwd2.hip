@@ -32,14 +32,15 @@ struct Cv2Cfg {
     static constexpr int HREC = (TH + 2) * HP;     // 612 records
     static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
     static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: a kernel row, or (64-channel tiles) the whole kernel
+    static constexpr int TPP = 3;                  // taps per phase: one kernel row
     static constexpr int NPH = 9 / TPP;            // phases per 32-channel chunk
     static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
     static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
     static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
-    static constexpr int SMEM = OFF_BIAS + 2 * 1024;
+    static constexpr int OFF_SCR = OFF_BIAS + 2 * 1024;         // per wave 2 KiB: the epilogue's [16 px][64 co] transposition tile
+    static constexpr int SMEM = OFF_SCR + 8 * 2048;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
@@ -297,11 +298,62 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             const int chan0 = second ? a.yoff2 + co_w - a.csplit : a.yoff + co_w;
             const size_t pix0 = ((size_t)cur.n * a.Hout + cur.h0 + wr * RW) * a.Wout + cur.w0;
             char* ybase = ydst + (pix0 * ld + chan0) * 2;                                // wave-uniform
-            const unsigned lane_off = (unsigned)(l15 * ld + 4 * g) * 2u;
+            if constexpr (FAST) {
+                // pass 1 (forward only): BN partial statistics of acc + bias
+                if (do_stats) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float b4[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (a.bias != nullptr) {
+                            const float4 bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
+                            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+                        }
+#pragma unroll
+                        for (int pg = 0; pg < NPG; ++pg)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { const float v = acc[ct][pg][r] + b4[r]; s1[r] += v; s2[r] += v * v; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t1 = wave_sum16(s1[r]);
+                            const float t2 = wave_sum16(s2[r]);
+                            if (l15 == 0) {
+                                red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 0] = t1;
+                                red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 1] = t2;
+                            }
+                        }
+                    }
+                }
+                // pass 2: every 16-pixel group goes through a wave-private LDS tile [16 px][64 co] (16-byte
+                // slots XORed with px & 7) and leaves as two stores of 8 pixels x 128 contiguous bytes:
+                // whole cache lines, instead of 64 scattered 8-byte pieces per instruction.
+                char* scr = smem + C::OFF_SCR + wave * 2048;
+                const int wpx = l15, rpx = lane >> 3, rch = lane & 7;
+                const unsigned st_off = (unsigned)(rpx * ld + rch * 8) * 2u;
+                const size_t row_stride = (size_t)a.Wout * ld * 2, half_stride = (size_t)8 * ld * 2;
+#pragma unroll
+                for (int pg = 0; pg < NPG; ++pg) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (a.bias != nullptr) bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
+                        uint2 pk;
+                        pk.x = Vec16<__bf16>::pk(acc[ct][pg][0] + bv.x, acc[ct][pg][1] + bv.y);
+                        pk.y = Vec16<__bf16>::pk(acc[ct][pg][2] + bv.z, acc[ct][pg][3] + bv.w);
+                        *(uint2*)(scr + wpx * 128 + (((ct * 2 + (g >> 1)) ^ (wpx & 7)) << 4) + (g & 1) * 8) = pk;
+                    }
+                    char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int px = h * 8 + rpx;
+                        const uint4 val = *(const uint4*)(scr + px * 128 + ((rch ^ (px & 7)) << 4));
+                        *(uint4*)(pp + h * half_stride) = val;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
                 const int co = co_w + ct * 16 + 4 * g;
-                const bool co_ok = FAST || co < a.Cout;
+                const bool co_ok = co < a.Cout;
                 float b4[4] = {0.f, 0.f, 0.f, 0.f};
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
                 if (a.bias != nullptr) {        // staged in LDS with the tile's first weights (zeros past Cout)
@@ -313,15 +365,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = acc[ct][pg][r] + b4[r];
-                    if constexpr (FAST) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { s1[r] += v[r]; s2[r] += v[r] * v[r]; }
-                        uint2 pk;
-                        pk.x = Vec16<__bf16>::pk(v[0], v[1]);
-                        pk.y = Vec16<__bf16>::pk(v[2], v[3]);
-                        char* bu = ybase + ((size_t)((pg >> 1) * a.Wout + (pg & 1) * 16) * ld + ct * 16) * 2;   // wave-uniform
-                        *(uint2*)(bu + lane_off) = pk;
-                    } else {
+                    {
                         const int ho = cur.h0 + wr * RW + (pg >> 1), wo = cur.w0 + (pg & 1) * 16 + l15;
                         if (co_ok && ho < a.Hout && wo < a.Wout) {
 #pragma unroll
@@ -356,6 +400,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                         }
                     }
                 }
+            }
             }
         };
         epilogue(std::integral_constant<bool, fast>{});
