@@ -138,7 +138,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     };
     // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
     auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot) {
+        int cnt = 0;
         if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) {
+            ++cnt;
             // the tile's biases ride with its first weights (wave 0, one piece; lanes past the block read zeros)
             const int nb = min(BCO, a.Cout - t.cb * BCO) * 4;
             lds_dma16_buf(make_rsrc(a.bias + t.cb * BCO, (unsigned)nb), (unsigned)lane * 16u,
@@ -160,8 +162,10 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 }
                 lds_dma16_buf(make_rsrc(wg + offu, LDS_DMA_RECORDS), v,
                               __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
+                ++cnt;
             }
         }
+        return cnt;
     };
     // input halo of one chunk: rows h0-pad .. +17, cols w0-pad .. +33, channels [c*32, c*32+32)
     auto issue_h = [&](const Tile& t, int c, int hstage, unsigned mask) {
@@ -201,29 +205,56 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     Cursor hq_ = wq_;                          // halo: advances chunk by chunk
     unsigned hmask = halo_mask(hq_.t);
     int wstage_i = 0, hstage_i = 0;
+    // Bookkeeping for counted waits: this wave's running count of DMA instructions and, per stage, the
+    // count right after the stage's last request.  vmcnt retires in order, so "stage X has landed" is
+    // "all but (n_issued - mark[X]) of my youngest requests are done".
+    int n_issued = 0, w_mark0 = 0, w_mark1 = 0, h_mark0 = 0, h_mark1 = 0;
     auto push_w = [&]() {
         if (!wq_.valid) return;
-        issue_w(wq_.t, wq_.c, wq_.ph, wstage_i, wq_.seq);
+        n_issued += issue_w(wq_.t, wq_.c, wq_.ph, wstage_i, wq_.seq);
+        if (wstage_i) w_mark1 = n_issued; else w_mark0 = n_issued;
         wstage_i ^= 1;
         if (++wq_.ph == NPH) { wq_.ph = 0; if (++wq_.c == nchunks) next_tile(wq_); }
     };
     auto push_h = [&]() {
-        if (!hq_.valid) return false;
+        if (!hq_.valid) return;
         issue_h(hq_.t, hq_.c, hstage_i, hmask);
+        n_issued += 5;
+        if (hstage_i) h_mark1 = n_issued; else h_mark0 = n_issued;
         hstage_i ^= 1;
         if (++hq_.c == nchunks) { next_tile(hq_); if (hq_.valid) hmask = halo_mask(hq_.t); }
-        return true;
     };
-    // prologue: phases 0 and 1 (and, for one-phase chunks, halo chunks 0 and 1)
+    // REFILL after the barrier that ends phase (c, ph): the weights two phases ahead go into the stage
+    // just freed; after a chunk's first phase also the next chunk's halo (weights first: the halo may
+    // then stay in flight past the next wait).
+    auto refill = [&](int ph_done) {
+        push_w();
+        if (ph_done == 0) push_h();
+    };
+    auto wait_landed = [&](int need) {
+        const int allowed = n_issued - need;      // my requests younger than the ones I need
+        if (allowed <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (allowed == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (allowed == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (allowed == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (allowed == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (allowed == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    };
+    // prologue: phases 0 and 1 and halo chunk 0
     push_w(); push_h(); push_w();
-    if (NPH == 1) push_h();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int tile_i = blockIdx.x, tseq = 0;
     Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
-    bool h_flying = false;     // a halo request that the next wait may leave in flight
+    // STAGGER: waves 0-3 refill right after the barrier, their SIMD partners (waves 4-7) in the middle of
+    // the next phase's MFMAs, so that on every SIMD one wave issues DMA while the other feeds the matrix pipe.
+    const bool late = wave >= 4;
+    int late_ph = -1;          // the refill waves 4-7 still owe (-1: none)
     for (;;) {
         f32x4 acc[4][NPG];
 #pragma unroll
@@ -257,6 +288,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #pragma unroll
                 for (int st = 0; st < NSTEP; ++st) {
                     const int kw = st / NPG, pg = st % NPG;      // kw: tap slot inside the phase
+                    if (st == NSTEP / 2 && late_ph >= 0) { refill(late_ph); late_ph = -1; }
                     if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
                     if (pg == NPG / 2 && kw + 1 < TPP) load_a(kw + 1, fa[(kw + 1) & 1]);
 #pragma unroll
@@ -264,19 +296,18 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                         acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
                 }
-                // ---- the next phase's operands have landed: a halo requested one phase ago (its five
-                // pieces are this wave's youngest requests) may stay in flight for one more phase -----
+                // ---- the next phase's weights (and, before a new chunk, its halo) must have landed; younger
+                // requests stay in flight across the barrier -----------------------------------------------
                 STAMP(2);
-                if (NPH == 3 && ph == 1 && h_flying) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                h_flying = false;
+                {
+                    int need = ws ? w_mark0 : w_mark1;
+                    if (ph == NPH - 1) need = max(need, hs ? h_mark0 : h_mark1);
+                    wait_landed(need);
+                }
                 STAMP(3);
                 __syncthreads();                        // everyone's pieces; and the stages just read are free
                 STAMP(4);
-                // ---- refill what was just freed: weights two phases ahead, then the halo -----------------
-                push_w();
-                if (NPH == 1) push_h();
-                else if (ph == 0) h_flying = push_h();
+                if (late) late_ph = ph; else refill(ph);
                 ws ^= 1;
                 STAMP(5);
             }
