@@ -32,15 +32,14 @@ struct Cv2Cfg {
     static constexpr int HREC = (TH + 2) * HP;     // 612 records
     static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
     static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int TPP = 3;                  // taps per phase: one kernel row
+    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: one kernel row; the whole kernel for 64-channel tiles
     static constexpr int NPH = 9 / TPP;            // phases per 32-channel chunk
     static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
     static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
     static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
-    static constexpr int OFF_SCR = OFF_BIAS + 2 * 1024;         // per wave 2 KiB: the epilogue's [16 px][64 co] transposition tile
-    static constexpr int SMEM = OFF_SCR + 8 * 2048;
+    static constexpr int SMEM = OFF_BIAS + 2 * 1024;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
@@ -227,6 +226,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // REFILL after the barrier that ends phase (c, ph): the weights two phases ahead go into the stage
     // just freed; after a chunk's first phase also the next chunk's halo (weights first: the halo may
     // then stay in flight past the next wait).
+    // The epilogue borrows, as its transposition tile, the two pieces of the halo stage just read that
+    // THIS wave refills (pieces wave and wave + 8); so at a tile's end a wave requests that halo only
+    // after its own epilogue (matters for one-phase chunks, where every barrier frees a halo stage).
     auto refill = [&](int ph_done) {
         push_w();
         if (ph_done == 0) push_h();
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         else if (allowed == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     };
-    // prologue: phases 0 and 1 and halo chunk 0
+    // prologue: phases 0 and 1 and halo chunk 0 (one-phase chunks: halo chunks 0 and 1)
     push_w(); push_h(); push_w();
+    if (NPH == 1) push_h();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // the next phase's MFMAs, so that on every SIMD one wave issues DMA while the other feeds the matrix pipe.
     const bool late = wave >= 4;
     int late_ph = -1;          // the refill waves 4-7 still owe (-1: none)
+    bool h_owed = false;       // waves 0-3, one-phase chunks: the halo request held back until after the epilogue
     for (;;) {
         f32x4 acc[4][NPG];
 #pragma unroll
@@ -285,17 +289,23 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 load_a(0, fa[0]);
 #pragma unroll
                 for (int s0 = 0; s0 < DEPTH; ++s0) fb[s0 % RING] = load_b(s0);
+                auto steps = [&](auto first_half) {
+                    constexpr int S0 = decltype(first_half)::value ? 0 : NSTEP / 2;
+                    constexpr int S1 = decltype(first_half)::value ? NSTEP / 2 : NSTEP;
 #pragma unroll
-                for (int st = 0; st < NSTEP; ++st) {
-                    const int kw = st / NPG, pg = st % NPG;      // kw: tap slot inside the phase
-                    if (st == NSTEP / 2 && late_ph >= 0) { refill(late_ph); late_ph = -1; }
-                    if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
-                    if (pg == NPG / 2 && kw + 1 < TPP) load_a(kw + 1, fa[(kw + 1) & 1]);
+                    for (int st = S0; st < S1; ++st) {
+                        const int kw = st / NPG, pg = st % NPG;      // kw: tap slot inside the phase
+                        if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
+                        if (pg == NPG / 2 && kw + 1 < TPP) load_a(kw + 1, fa[(kw + 1) & 1]);
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
-                }
+                        for (int ct = 0; ct < 4; ++ct)
+                            acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+                    }
+                };
+                steps(std::true_type{});
+                if (late_ph >= 0) { refill(late_ph); late_ph = -1; }      // waves 4-7: the refill they owe
+                steps(std::false_type{});
                 // ---- the next phase's weights (and, before a new chunk, its halo) must have landed; younger
                 // requests stay in flight across the barrier -----------------------------------------------
                 STAMP(2);
@@ -307,7 +317,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 STAMP(3);
                 __syncthreads();                        // everyone's pieces; and the stages just read are free
                 STAMP(4);
-                if (late) late_ph = ph; else refill(ph);
+                if (late) late_ph = ph;
+                else if (NPH == 1 && c + 1 == nchunks) { push_w(); h_owed = true; }     // halo after the epilogue
+                else refill(ph);
                 ws ^= 1;
                 STAMP(5);
             }
@@ -357,7 +369,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // pass 2: every 16-pixel group goes through a wave-private LDS tile [16 px][64 co] (16-byte
                 // slots XORed with px & 7) and leaves as two stores of 8 pixels x 128 contiguous bytes:
                 // whole cache lines, instead of 64 scattered 8-byte pieces per instruction.
-                char* scr = smem + C::OFF_SCR + wave * 2048;
+                // (hs was toggled after the chunk loop: the stage just read is hs ^ 1)
+                char* scr = smem + (hs ^ 1) * C::H_BYTES + wave * 1024;
                 const int wpx = l15, rpx = lane >> 3, rch = lane & 7;
                 const unsigned st_off = (unsigned)(rpx * ld + rch * 8) * 2u;
                 const size_t row_stride = (size_t)a.Wout * ld * 2, half_stride = (size_t)8 * ld * 2;
@@ -370,13 +383,13 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                         uint2 pk;
                         pk.x = Vec16<__bf16>::pk(acc[ct][pg][0] + bv.x, acc[ct][pg][1] + bv.y);
                         pk.y = Vec16<__bf16>::pk(acc[ct][pg][2] + bv.z, acc[ct][pg][3] + bv.w);
-                        *(uint2*)(scr + wpx * 128 + (((ct * 2 + (g >> 1)) ^ (wpx & 7)) << 4) + (g & 1) * 8) = pk;
+                        *(uint2*)(scr + (wpx >> 3) * 8192 + (wpx & 7) * 128 + (((ct * 2 + (g >> 1)) ^ (wpx & 7)) << 4) + (g & 1) * 8) = pk;
                     }
                     char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int px = h * 8 + rpx;
-                        const uint4 val = *(const uint4*)(scr + px * 128 + ((rch ^ (px & 7)) << 4));
+                        const uint4 val = *(const uint4*)(scr + h * 8192 + rpx * 128 + ((rch ^ rpx) << 4));
                         *(uint4*)(pp + h * half_stride) = val;
                     }
                 }
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             }
         };
         epilogue(std::integral_constant<bool, fast>{});
+        if (h_owed) { push_h(); h_owed = false; }
         if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
