@@ -59,7 +59,11 @@ struct Wg2Cfg {
     static_assert((HWD * REC) % 256 == 0, "row pitch must keep the bank phase");
 };
 
-template <int KH, int KW, int SH, int WT, int TH>
+// GEN = false: channel counts multiples of the block and the output a whole number of tiles (every U-Net
+// layer): the DMA is one buffer_load ... lds per piece with a wave-uniform descriptor (tile origin) and
+// per-lane offsets fixed for the kernel's life; image borders use the out-of-range offset (hardware
+// writes zeros).  GEN = true: every bound checked per lane, zero block as the padded source.
+template <int KH, int KW, int SH, int WT, int TH, bool GEN>
 __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan, FastDiv d_tw, FastDiv d_th) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     constexpr int REC = C::REC, SLOTS = C::SLOTS, RPP = C::RPP, HWD = C::HWD, NT = C::NT, CT = C::CT;
@@ -112,8 +116,59 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
 
-    // One tile's DMA: every wave issues its share of the 1-KiB pieces of both images.
-    auto issue = [&](int tile, int stage_off) {
+    // ---- fast DMA plan -------------------------------------------------------------------------------
+    constexpr int DZ_PW = (C::DZ_PIECES + 7) / 8, X_PW = (C::X_PIECES + 7) / 8;
+    unsigned dz_l[DZ_PW], x_l[X_PW];
+    if constexpr (!GEN) {
+        const int rl = lane / SLOTS, s = lane % SLOTS;
+#pragma unroll
+        for (int i = 0; i < DZ_PW; ++i) {
+            const int R = (wave + 8 * i) * RPP + rl;
+            const int r = R >> 5, c = R & 31;
+            dz_l[i] = (unsigned)((r * a.Wout + c) * a.lddz + (s ^ (swz_bytes<REC>(c) >> 4)) * 8) * 2u;
+        }
+#pragma unroll
+        for (int i = 0; i < X_PW; ++i) {
+            const int R = (wave + 8 * i) * RPP + rl;
+            const int hr = R / HWD, hc = R - hr * HWD;
+            x_l[i] = R < C::X_REC ? (unsigned)((hr * a.Win + hc) * a.ldx + (s ^ (swz_bytes<REC>(hc) >> 4)) * 8) * 2u : LDS_DMA_OOB;
+        }
+    }
+    auto issue_fast = [&](int tile, int stage_off) {
+        const int p1 = (int)fdiv((unsigned)tile, d_tw), tw_i = tile - p1 * a.tiles_w;
+        const int n = (int)fdiv((unsigned)p1, d_th), th_i = p1 - n * a.tiles_h;
+        const int h0 = th_i * TH, w0 = tw_i * C::TW;
+        const int row0 = h0 * SH - a.pad_h, col0 = w0 - a.pad_w;
+        const i32x4_t rdz = make_rsrc(dzp + ((long long)(n * a.Hout + h0) * a.Wout + w0) * a.lddz, LDS_DMA_RECORDS);
+        const i32x4_t rx = make_rsrc(xp + ((long long)(n * a.Hin + row0) * a.Win + col0) * a.ldx, LDS_DMA_RECORDS);
+        unsigned mask = ~0u;
+        if (!(row0 >= 0 && row0 + C::HH <= a.Hin && col0 >= 0 && col0 + HWD <= a.Win)) {      // border tile (wave-uniform)
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            mask = 0;
+#pragma unroll
+            for (int i = 0; i < X_PW; ++i) {
+                const int R = (wave + 8 * i) * RPP + lane_ / SLOTS;
+                const int hr = R / HWD, hc = R - hr * HWD;
+                if ((unsigned)(row0 + hr) < (unsigned)a.Hin && (unsigned)(col0 + hc) < (unsigned)a.Win) mask |= 1u << i;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DZ_PW; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece < C::DZ_PIECES)
+                lds_dma16_buf(rdz, dz_l[i], __builtin_amdgcn_readfirstlane(smem_base + stage_off + piece * 1024));
+        }
+#pragma unroll
+        for (int i = 0; i < X_PW; ++i) {
+            const int piece = wave + 8 * i;
+            if (piece < C::X_PIECES)
+                lds_dma16_buf(rx, ((mask >> i) & 1u) ? x_l[i] : LDS_DMA_OOB,
+                              __builtin_amdgcn_readfirstlane(smem_base + stage_off + C::DZ_BYTES + piece * 1024));
+        }
+    };
+    // One tile's DMA, generic form: every wave issues its share of the 1-KiB pieces of both images.
+    auto issue_gen = [&](int tile, int stage_off) {
         const int p1 = (int)fdiv((unsigned)tile, d_tw), tw_i = tile - p1 * a.tiles_w;
         const int n = (int)fdiv((unsigned)p1, d_th), th_i = p1 - n * a.tiles_h;
         const int h0 = th_i * TH, w0 = tw_i * C::TW;
@@ -152,6 +207,9 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
         }
     };
 
+    auto issue = [&](int tile, int stage_off) {
+        if constexpr (GEN) issue_gen(tile, stage_off); else issue_fast(tile, stage_off);
+    };
     if (t_begin < t_end) issue(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -217,12 +275,12 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             }
 }
 
-template <int KH, int KW, int SH, int WT, int TH>
-static int launch_wgrad2(WgradArgs a, hipStream_t stream, int nsplit) {
+template <int KH, int KW, int SH, int WT, int TH, bool GEN>
+static int launch_wgrad2g(WgradArgs a, hipStream_t stream, int nsplit) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
         attr_done = true;
@@ -233,10 +291,17 @@ static int launch_wgrad2(WgradArgs a, hipStream_t stream, int nsplit) {
     const int nco = (a.Cout + C::CT - 1) / C::CT, nci = (a.Cin + C::CT - 1) / C::CT;
     UNET_CHECK((unsigned long long)a.tiles_total * (unsigned)(a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH>), dim3((unsigned)(nsplit * nco * nci)), dim3(512), C::SMEM, stream,
+    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>), dim3((unsigned)(nsplit * nco * nci)), dim3(512), C::SMEM, stream,
                        a, nci, nco * nci, make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
+}
+
+template <int KH, int KW, int SH, int WT, int TH>
+static int launch_wgrad2(const WgradArgs& a, hipStream_t stream, int nsplit) {
+    constexpr int CT = 32 * WT;
+    const bool gen = (a.Cout % CT) != 0 || (a.Cin % CT) != 0 || (a.Hout % TH) != 0 || (a.Wout & 31) != 0;
+    return gen ? launch_wgrad2g<KH, KW, SH, WT, TH, true>(a, stream, nsplit) : launch_wgrad2g<KH, KW, SH, WT, TH, false>(a, stream, nsplit);
 }
 
 // geometry of the bf16 path for (kh, kw, stride): channel tile and rows per K tile
