@@ -149,7 +149,7 @@ def test_conv_split_output(dev, dt, geom):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("shape", [(2, 6, 10, 32, 16), (1, 16, 32, 128, 64), (2, 3, 5, 16, 8)])
+@pytest.mark.parametrize("shape", [(2, 6, 10, 32, 16), (1, 16, 32, 128, 64), (2, 3, 5, 16, 8), (2, 32, 64, 256, 128), (1, 32, 32, 128, 64)])
 def test_conv_transpose(dev, dt, shape):
     ops = ops_mod()
     N, h, w_, Ci, Co = shape

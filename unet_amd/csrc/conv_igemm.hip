@@ -252,6 +252,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 // bf16 3x3 stride-1 path (conv_fwd2.hip)
 int conv2_tiles(int N, int Hout, int Wout);
 int dispatch_conv2(const ConvArgs& a, hipStream_t s);
+// bf16 ConvTranspose2d forward / dgrad on whole tiles (conv_t2.hip)
+bool convT2_fwd_ok(const ConvArgs& a);
+int convT2_fwd(const ConvArgs& a, hipStream_t s);
+bool convT2_dgrad_ok(const ConvArgs& a);
+int convT2_dgrad(const ConvArgs& a, hipStream_t s);
 static bool use_conv2(int dtype, int kh, int kw, int sh, int epi) {
     return dtype == UNET_BF16 && kh == 3 && kw == 3 && sh == 1 && epi == 0;
 }
@@ -314,6 +319,8 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
         UNET_CHECK((size_t)9 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");
         return dispatch_conv2(a, s);
     }
+    if (dtype == UNET_BF16 && epi == 1 && kh == 1 && kw == 1 && stride_h == 1 && convT2_fwd_ok(a)) return convT2_fwd(a, s);
+    if (dtype == UNET_BF16 && epi == 0 && kh == 2 && kw == 1 && stride_h == 2 && convT2_dgrad_ok(a)) return convT2_dgrad(a, s);
     return dtype == UNET_BF16 ? dispatch_conv<__bf16>(kh, kw, stride_h, epi, a, s)
                               : dispatch_conv<float>(kh, kw, stride_h, epi, a, s);
 }
