@@ -65,6 +65,16 @@ class ConvTimer:
         return fl, ms, n
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot
+    run inside this process): tools/pmc_bench.sh -> profiles/r01_pmc_traffic.json; None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sample_images=2, size=512, iters=2):
     """Oracle fwd + loss + bwd on the host cores (fp32), bounded sample of the same workload."""
     from oracle import loss_ref, unet_ref
@@ -174,7 +184,7 @@ def main():
             fl, ms, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
                                "kernel": "conv3x3_v2_kernel<WC,GEN> (bf16 3x3 fwd + dgrad launches)",
                                "launches": n, "avg_launch_ms": ms / n, "avg_launch_gflop": fl / n / 1e9}
             out["train_step_tflops"] = TRAIN_GFLOP_PER_IMAGE_512 * (args.size / 512.0) ** 2 * value / 1e3
