@@ -301,10 +301,13 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                         for (int ct = 0; ct < 4; ++ct)
                             acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the fragment requests DEPTH steps ahead of their MFMAs
                     }
                 };
                 steps(std::true_type{});
+                STAMP(7);
                 if (late_ph >= 0) { refill(late_ph); late_ph = -1; }      // waves 4-7: the refill they owe
+                STAMP(8);
                 steps(std::false_type{});
                 // ---- the next phase's weights (and, before a new chunk, its halo) must have landed; younger
                 // requests stay in flight across the barrier -----------------------------------------------
