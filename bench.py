@@ -133,7 +133,8 @@ def main():
     model = REGISTRY["unet"](in_channels=1, n_classes=2, features=[64, 128, 256, 512]).to(dev).train()
     if world > 1:
         model = DataParallel(model, device_ids=[local_rank])
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    from unet_amd.utils.builders import get_optim          # the reference's builder API (utils/builders.py:128-146)
+    opt = get_optim("adamw", [p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
     trainer = types.SimpleNamespace(
         optimizer=opt, amp=(args.dtype == "bf16"), model=model, grad_clip=1.0, cbs=[], current_epoch=1,
         logger=logging.getLogger("bench"),

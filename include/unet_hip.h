@@ -78,6 +78,25 @@ int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, i
 /* fp32 master weights -> packed compute-dtype images.  mode 0 conv fwd, 1 conv dgrad (flipped,
  * transposed), 2 convT fwd, 3 convT dgrad.  O,I = dims 0,1 of the source tensor. */
 int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, int I, int ntaps, void* stream);
+/* The same for n tensors in one launch per 40 tensors (HOST arrays; they travel as kernel arguments). */
+int unet_pack_weights_multi(int dtype, int nt, const int* modes, const void* const* src, void* const* dst,
+                            const int* O, const int* I, const int* ntaps, void* stream);
+
+/* ---- optimizer tail of step_batch ------------------------------------------------------------
+ * utils/train_step.py:56-63 (scaler.unscale_ -> clip_grad_norm_ -> optimizer.step) with the AdamW of
+ * utils/builders.py:143-146, as multi-tensor kernels over fp32 tensors.  The tensor lists are HOST
+ * arrays of device pointers.  unet_grad_sumsq writes one fp64 partial per 16384-element chunk
+ * (unet_mt_blocks of them); unet_grad_norm_finalize sums them in a fixed order and writes
+ * norm_out[0] = ||g||_2 and norm_out[1] = min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_'s
+ * coefficient) on the device.  unet_adamw_step multiplies the gradients by norm_out[1] (NULL: no
+ * clipping; write_grads: store the clipped gradients back as clip_grad_norm_ does) and applies
+ * torch.optim.AdamW's update for step number `step` (>= 1) to every tensor. */
+int unet_mt_blocks(int nt, const long long* numel);
+int unet_grad_sumsq(int nt, const void* const* grads, const long long* numel, double* partials, void* stream);
+int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float* norm_out, void* stream);
+int unet_adamw_step(int nt, void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                    const long long* numel, const float* norm_out, int write_grads, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, long long step, void* stream);
 int unet_cast(int dtype, int to_f32, const void* src, void* dst, long long n, void* stream);
 
 /* ---- BatchNorm2d (+ReLU) -- models/unet.py:11-12,14-15 --------------------------------------

@@ -130,15 +130,19 @@ def test_unet_bf16_within_stated_tolerance(dev, name):
         assert e_hip <= 1.6 * e_emu + 1e-2, (k, e_hip, e_emu)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("name", ["unet_f8x16", "unet_f8x16x32x64"])
-def test_step_batch_matches_reference(dev, name):
-    """zero_grad -> fwd -> loss -> bwd -> clip 1.0 -> AdamW(1e-4, wd 1e-4): parameters after one step."""
+def test_step_batch_matches_reference(dev, name, fused):
+    """zero_grad -> fwd -> loss -> bwd -> clip 1.0 -> AdamW(1e-4, wd 1e-4): parameters after one step,
+    with torch's AdamW and with the fused multi-tensor tail that get_optim("adamw") builds."""
     import logging
     from unet_amd.losses import get_loss
+    from unet_amd.utils.builders import get_optim
     from unet_amd.utils.train_step import step_batch
     m, g = build(name, dev)
     m.train()
-    opt = torch.optim.AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+    make = (lambda ps, **kw: get_optim("adamw", ps, **kw)) if fused else torch.optim.AdamW
+    opt = make([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
     tr = types.SimpleNamespace(optimizer=opt, amp=False, model=m, grad_clip=1.0, cbs=[], current_epoch=1,
                                logger=logging.getLogger("t"),
                                loss_fn=get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255))

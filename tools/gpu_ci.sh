@@ -15,6 +15,7 @@ run() {   # name timeout cmd...
 for step in "$@"; do
   case $step in
     kernels) run kernels 900 python -u -m pytest tests/test_gpu_kernels.py -m gpu -q --timeout 120 --timeout-method thread --tb=short -p no:cacheprovider ;;
+    optim)   run optim 300 python -u -m pytest tests/test_gpu_optim.py -m gpu -q --timeout 120 --timeout-method thread --tb=short -p no:cacheprovider ;;
     model)   run model 600 python -u -m pytest tests/test_gpu_model.py -m gpu -q --timeout 180 --timeout-method thread --tb=short -p no:cacheprovider ;;
     all)     run all 1100 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread --tb=short -p no:cacheprovider ;;
     smoke)   run smoke 300 python -u -c "import __graft_entry__ as g; g.smoke()" ;;

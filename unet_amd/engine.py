@@ -56,6 +56,24 @@ class UNetEngine:
         self._packed[key] = (ver, t)
         return t
 
+    def prepack(self, P, dt):
+        """Refresh, in ONE launch, every packed image this engine has used before whose parameter has changed
+        since (i.e. after an optimizer step: all of them).  First use of an image still goes through packed()."""
+        stale = []
+        for key, (ver, t) in self._packed.items():
+            name, mode, kdt = key
+            p = P.get(name)
+            if kdt != dt or p is None or (p._version, p.data_ptr()) == ver:
+                continue
+            if (p.numel() != t.numel() or p.device != t.device or p.dtype != torch.float32
+                    or not p.is_contiguous() or p.dim() != 4):
+                continue                      # packed() re-creates it
+            stale.append((key, p, mode, t))
+        if stale:
+            ops.pack_weights_multi([(p.detach(), mode, t) for _, p, mode, t in stale], dt)
+            for key, p, mode, t in stale:
+                self._packed[key] = ((p._version, p.data_ptr()), t)
+
     # ------------------------------------------------------------------ forward
     def _conv_bn_relu(self, P, B, prefix, idx, xin, yout: Optional[Act], dt, train, save, first=False, x_f32=None):
         """conv3x3(+bias) -> BN -> ReLU.  Returns (y Act, saved record)."""
@@ -110,6 +128,7 @@ class UNetEngine:
             # the reference falls into a bilinear-resize branch here (models/unet.py:56-57); not built
             raise ops.UNetHipError(f"H and W must be divisible by {1 << L} (got {H}x{W})")
         dev = x.device
+        self.prepack(P, dt)
         x = x.detach()
         if x.dtype != torch.float32:
             x = x.float()

@@ -105,6 +105,80 @@ def pack_weights(w: torch.Tensor, mode: int, dt: int) -> torch.Tensor:
     return out
 
 
+def pack_weights_multi(items, dt: int):
+    """items: [(fp32 weight, mode, destination tensor)] -> every packed image refreshed in one launch per 40."""
+    import ctypes
+    n = len(items)
+    if n == 0:
+        return
+    srcs, dsts, modes, Os, Is, NTs = [], [], [], [], [], []
+    for w, mode, out in items:
+        _need_cuda(w, out)
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 4:
+            raise UNetHipError("pack_weights_multi: weights must be contiguous 4-D fp32 tensors")
+        if out.numel() != w.numel() or out.dtype != _TORCH_DT[dt] or not out.is_contiguous():
+            raise UNetHipError("pack_weights_multi: destination does not match the weight")
+        srcs.append(w.data_ptr()); dsts.append(out.data_ptr()); modes.append(mode)
+        Os.append(w.shape[0]); Is.append(w.shape[1]); NTs.append(w.shape[2] * w.shape[3])
+    IA, PA = ctypes.c_int * n, ctypes.c_void_p * n
+    check(lib().unet_pack_weights_multi(dt, n, IA(*modes), PA(*srcs), PA(*dsts), IA(*Os), IA(*Is), IA(*NTs), _stream()),
+          "pack_weights_multi")
+
+
+# ----------------------------------------------------------------------------- optimizer tail
+
+def _f32_list(ts, what):
+    for t in ts:
+        if not t.is_cuda:
+            raise UNetHipError("unet_amd runs on MI355X only: got a CPU tensor (there is no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.is_sparse:
+            raise UNetHipError(f"{what}: tensors must be dense contiguous fp32")
+
+
+def mt_blocks(numels) -> int:
+    import ctypes
+    n = len(numels)
+    r = lib().unet_mt_blocks(n, (ctypes.c_longlong * n)(*numels))
+    if r < 0:
+        raise UNetHipError("mt_blocks: too many elements")
+    return r
+
+
+def grad_norm(grads, max_norm: float, partials: torch.Tensor, norm_out: torch.Tensor):
+    """Global L2 norm of `grads` and clip_grad_norm_'s coefficient, on the device:
+    norm_out[0] = norm, norm_out[1] = min(1, max_norm / (norm + 1e-6))."""
+    import ctypes
+    _f32_list(grads, "grad_norm")
+    n = len(grads)
+    numels = [g.numel() for g in grads]
+    nb = mt_blocks(numels)
+    if partials.dtype != torch.float64 or partials.numel() < nb or norm_out.dtype != torch.float32 or norm_out.numel() < 2:
+        raise UNetHipError("grad_norm: workspace too small")
+    NA = (ctypes.c_longlong * n)(*numels)
+    check(lib().unet_grad_sumsq(n, (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]), NA, _p(partials), _stream()), "grad_sumsq")
+    check(lib().unet_grad_norm_finalize(_p(partials), nb, float(max_norm), _p(norm_out), _stream()), "grad_norm_finalize")
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, norm_out: Optional[torch.Tensor], write_grads: bool,
+               lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int):
+    import ctypes
+    n = len(params)
+    if not (len(grads) == len(exp_avg) == len(exp_avg_sq) == n):
+        raise UNetHipError("adamw_step: list lengths differ")
+    for lst in (params, grads, exp_avg, exp_avg_sq):
+        _f32_list(lst, "adamw_step")
+    numels = [p.numel() for p in params]
+    for g, m, v, k in zip(grads, exp_avg, exp_avg_sq, numels):
+        if g.numel() != k or m.numel() != k or v.numel() != k:
+            raise UNetHipError("adamw_step: parameter / gradient / state sizes differ")
+    PA = ctypes.c_void_p * n
+    check(lib().unet_adamw_step(n, PA(*[t.data_ptr() for t in params]), PA(*[t.data_ptr() for t in grads]),
+                                PA(*[t.data_ptr() for t in exp_avg]), PA(*[t.data_ptr() for t in exp_avg_sq]),
+                                (ctypes.c_longlong * n)(*numels), _p(norm_out), int(bool(write_grads)),
+                                float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _stream()),
+          "adamw_step")
+
+
 # ----------------------------------------------------------------------------- convolutions
 
 def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act, kh: int, kw: int,

@@ -33,7 +33,8 @@ def build_loss(loss_name, loss_args, device):
 def get_optim(name, params, **kw):
     name = name.lower()
     if name == "adamw":
-        return torch.optim.AdamW(params, **kw)
+        from ..optim import FusedAdamW          # a torch.optim.AdamW whose step() is the fused HIP kernel
+        return FusedAdamW(params, **kw)
     if name == "adam":
         return torch.optim.Adam(params, **kw)
     if name == "sgd":

@@ -5,6 +5,8 @@
     -> trainer._global_step += 1 -> info{'main_loss','lr'} -> on_batch_end callbacks
 
 Differences: autocast selects the bf16 HIP kernels (the reference's fp16 autocast has no bf16 path);
+with `unet_amd.optim.FusedAdamW` (what `get_optim("adamw")` builds) and a disabled GradScaler the
+clip + optimizer tail is the fused multi-tensor path;
 the one host sync that fetches `main_loss` also carries the loss kernel's illegal-label counter, so a
 label the reference would have raised on still raises here.
 """
@@ -45,11 +47,15 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
     if sync is not None:          # data-parallel wrapper: wait for the bucketed all-reduces
         sync()
 
-    if trainer.grad_clip > 0:
-        scaler.unscale_(trainer.optimizer)
-        torch.nn.utils.clip_grad_norm_(trainer.model.parameters(), trainer.grad_clip)
-
-    scaler.step(trainer.optimizer)
+    fused = getattr(trainer.optimizer, "clip_and_step", None)
+    if fused is not None and not scaler.is_enabled() and trainer.grad_clip > 0:
+        # unet_amd.optim.FusedAdamW: norm -> clip -> AdamW in two multi-tensor passes, no host sync
+        fused(trainer.model.parameters(), trainer.grad_clip)
+    else:
+        if trainer.grad_clip > 0:
+            scaler.unscale_(trainer.optimizer)
+            torch.nn.utils.clip_grad_norm_(trainer.model.parameters(), trainer.grad_clip)
+        scaler.step(trainer.optimizer)
     scaler.update()
 
     step_idx = int(getattr(trainer, "_global_step", 0)) + 1
