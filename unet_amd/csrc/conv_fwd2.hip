@@ -200,7 +200,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         if (q.valid) q.t = decode(q.tile_i);
     };
     if ((int)blockIdx.x >= total_tiles) return;
-    Cursor wq_ = cursor_at(blockIdx.x);        // weights: advances phase by phase
+    const int lblock = xcd_block_id();
+    Cursor wq_ = cursor_at(lblock);        // weights: advances phase by phase
     Cursor hq_ = wq_;                          // halo: advances chunk by chunk
     unsigned hmask = halo_mask(hq_.t);
     int wstage_i = 0, hstage_i = 0;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    int tile_i = blockIdx.x, tseq = 0;
+    int tile_i = lblock, tseq = 0;
     Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
     // STAGGER: waves 0-3 refill right after the barrier, their SIMD partners (waves 4-7) in the middle of

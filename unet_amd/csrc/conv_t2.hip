@@ -75,7 +75,8 @@ __global__ __launch_bounds__(512) void convT2_kernel(CT2Args a, FastDiv d_n, Fas
         return o;
     };
     // ---- issue side ---------------------------------------------------------------------------------
-    int q_tile = blockIdx.x, q_k = 0, q_seq = 0, q_stage = 0;
+    const int lblock = xcd_block_id();
+    int q_tile = lblock, q_k = 0, q_seq = 0, q_stage = 0;
     bool q_valid = q_tile < a.total_tiles;
     Tile q_t = decode(q_valid ? q_tile : 0);
     int n_issued = 0, mark[3] = {0, 0, 0};
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(512) void convT2_kernel(CT2Args a, FastDiv d_n, Fas
     wait_landed(mark[0]);
     __syncthreads();
 
-    int tile_i = blockIdx.x, tseq = 0, s = 0;
+    int tile_i = lblock, tseq = 0, s = 0;
     Tile cur = decode(tile_i);
     for (;;) {
         f32x4 acc[4][8];

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     constexpr int WM = C::WM, WN = C::WN;
 
     // channel block fastest: resident workgroups share the pixel range
-    const int chan = blockIdx.x % nchan, split = blockIdx.x / nchan;
+    const int lblock = xcd_block_id();
+    const int chan = lblock % nchan, split = lblock / nchan;
     const int co0 = (chan / nchan_ci) * CT, ci0 = (chan % nchan_ci) * CT;
     const int wco = (wave >> 2) * (16 * WM), wci = (wave & 3) * (16 * WN);
 

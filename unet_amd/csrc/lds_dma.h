@@ -49,3 +49,11 @@ static inline FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 __device__ __forceinline__ unsigned fdiv(unsigned x, FastDiv f) { return f.magic ? __umulhi(x, f.magic) : x; }
+
+// Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a contiguous run
+// of LOGICAL block ids instead, so that blocks working on the same pixels (other channel blocks) or on
+// neighbouring tiles share one L2 rather than fetching the same lines into eight of them.
+__device__ __forceinline__ int xcd_block_id() {
+    const int g = (int)gridDim.x, b = (int)blockIdx.x;
+    return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
+}
