@@ -210,8 +210,10 @@ class UNetEngine:
         if split_f:
             dskip = ops.dense(z1.N, z1.H, z1.W, split_f, dt, dev)
             dup = ops.dense(z1.N, z1.H, z1.W, Cin - split_f, dt, dev)
-            ops.conv_fwd(dz1, wd, None, dskip, 3, 3, w1.shape[0], Cin, y2=dup, csplit=split_f)
-            return dskip, dup
+            # per-tile channel sums of the epilogue (the fp32 values before rounding): their upper half is the
+            # bias gradient of the transposed conv that produced `up`, so no extra pass over dup is needed
+            rows = ops.conv_fwd(dz1, wd, None, dskip, 3, 3, w1.shape[0], Cin, y2=dup, csplit=split_f, stats=True)
+            return dskip, dup, rows
         dx = ops.dense(z1.N, z1.H, z1.W, Cin, dt, dev)
         ops.conv_fwd(dz1, wd, None, dx, 3, 3, w1.shape[0], Cin)
         return dx
@@ -237,12 +239,19 @@ class UNetEngine:
         for j in reversed(range(L)):
             f = list(reversed(self.features))[j]
             p = f"ups.{2 * j + 1}"
-            dskip, dup = self.block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
+            res = self.block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
+            dskip, dup = res[0], res[1]
             emit(self.block_param_names(p))
             dskips[L - 1 - j] = dskip
             xin = sv.up_in[j]
             tname = f"ups.{2 * j}"
-            grads[tname + ".bias"] = ops.channel_sum(dup, ws)
+            if len(res) > 2:        # [tiles][2f][sum, sum of squares] from the dgrad epilogue
+                rows = res[2]
+                ctot = rows.shape[1]
+                sums = ops.channel_sum(ops.Act(rows.view(1, 1, rows.shape[0], ctot * 2), 2 * f, 2 * (ctot - f)), ws)
+                grads[tname + ".bias"] = sums.view(-1, 2)[:, 0].contiguous()
+            else:
+                grads[tname + ".bias"] = ops.channel_sum(dup, ws)
             grads[tname + ".weight"] = ops.convT_wgrad(xin, dup, ws)
             dcur = ops.dense(xin.N, xin.H, xin.W, xin.C, dt, dev)
             ops.convT_dgrad(dup, self.packed(tname + ".weight", P[tname + ".weight"], 3, dt), xin.C, dcur)
