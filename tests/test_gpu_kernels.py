@@ -202,6 +202,30 @@ def test_first_conv(dev, dt, k, cin):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(3, 40, 70, 64), (1, 16, 32, 8), (2, 33, 31, 128), (1, 64, 64, 32)])
+def test_first_conv_cin1_strips(dev, dt, shape):
+    """The Cin=1 3x3 sliding-window kernels: several 16-row strips, ragged right / bottom edges, idle lanes."""
+    ops = ops_mod()
+    N, H, W, Cout = shape
+    x = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(21))
+    w = rnd((Cout, 1, 3, 3), 22, 0.3)
+    b = rnd((Cout,), 23)
+    w.requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=1)
+    dyv = q(rnd(tuple(ref.shape), 24), dt)
+    ref.backward(dyv)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    z = ops.dense(N, H, W, Cout, dt, dev)
+    rows = ops.conv_first_fwd(xh, w.detach().to(dev), b.to(dev), z, 3, 3)
+    close(from_act(z), ref.detach(), dt, "first conv fwd")
+    s = rows.double().sum(0).cpu()
+    close(s[:, 0].float(), ref.detach().double().sum((0, 2, 3)).float(), dt, "first conv stats", f32_out=True)
+    close(s[:, 1].float(), (ref.detach().double() ** 2).sum((0, 2, 3)).float(), dt, "first conv sumsq", f32_out=True)
+    dw = ops.conv_first_wgrad(to_act(dyv, dt, dev), xh, 3, 3, ops.Workspace(dev))
+    close(dw.cpu(), w.grad, dt, "first conv wgrad", f32_out=True)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("C,K", [(64, 2), (8, 3), (24, 2), (16, 8)])
 def test_final_conv(dev, dt, C, K):
     ops = ops_mod()

@@ -138,6 +138,147 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cin == 1, 3x3 (the reference's CT configuration, models/unet.py:30 with in_channels=1): both kernels keep
+// the thread's weights / weight-gradient partials in registers and walk DOWN a column strip with a sliding
+// 3x3 window, so a pixel costs 3 input loads instead of 9 and no LDS traffic.  Thread = (pixel lane, group
+// of EPV output channels); a workgroup covers PL = 256/(Cout/EPV) adjacent columns x FIRST_R rows per tile.
+constexpr int FIRST_R = 16;
+
+__device__ __forceinline__ void first_row3(const float* __restrict__ xi, int hh, int wq, int H, int W, float* r) {
+    const bool rowok = (unsigned)hh < (unsigned)H;
+    const float* xr = xi + (long long)hh * W;
+    r[0] = (rowok && wq >= 1) ? xr[wq - 1] : 0.f;
+    r[1] = rowok ? xr[wq] : 0.f;
+    r[2] = (rowok && wq + 1 < W) ? xr[wq + 1] : 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, T* __restrict__ z,
+                                                              float* __restrict__ stats, int H, int W, int Cout) {
+    constexpr int EPV = TT<T>::EPV;
+    __shared__ float red[256 * EPV * 2];
+    const int G = Cout / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    float wr[9][EPV], b[EPV], s1[EPV], s2[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        s1[e] = s2[e] = 0.f;
+        b[e] = (bias != nullptr && active) ? bias[cg * EPV + e] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t][e] = active ? w[(cg * EPV + e) * 9 + t] : 0.f;
+    }
+    const int tiles_w = (W + PL - 1) / PL, tiles_h = (H + FIRST_R - 1) / FIRST_R;
+    const float* xi = x + (long long)blockIdx.y * H * W;
+    T* zi = z + (long long)blockIdx.y * H * W * Cout;
+    for (int tile = blockIdx.x; tile < tiles_w * tiles_h; tile += gridDim.x) {
+        const int th = tile / tiles_w, tw = tile - th * tiles_w;
+        const int h0 = th * FIRST_R, wq = tw * PL + pl;
+        if (!active || wq >= W) continue;
+        const int h1 = min(h0 + FIRST_R, H);
+        float ra[3], rb[3], rc[3];
+        first_row3(xi, h0 - 1, wq, H, W, ra);
+        first_row3(xi, h0, wq, H, W, rb);
+        for (int h = h0; h < h1; ++h) {
+            first_row3(xi, h + 1, wq, H, W, rc);
+            float acc[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float v = b[e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    v = fmaf(ra[k], wr[k][e], v);
+                    v = fmaf(rb[k], wr[3 + k][e], v);
+                    v = fmaf(rc[k], wr[6 + k][e], v);
+                }
+                acc[e] = v;
+                s1[e] += v; s2[e] = fmaf(v, v, s2[e]);
+            }
+            *(uint4*)(zi + ((long long)h * W + wq) * Cout + cg * EPV) = Vec16<T>::pack(acc);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+        }
+    }
+    if (stats != nullptr) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                red[(pl * Cout + cg * EPV + e) * 2 + 0] = s1[e];
+                red[(pl * Cout + cg * EPV + e) * 2 + 1] = s2[e];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < Cout * 2; i += 256) {
+            float s = 0.f;
+            for (int p = 0; p < PL; ++p) s += red[p * Cout * 2 + i];
+            stats[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Cout * 2 + i] = s;
+        }
+    }
+}
+
+// dW[co][tap] = sum_p dz[p][co] * x[p + tap]; fp64 atomics into acc[Cout][9]
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first1_wgrad_kernel(const T* __restrict__ dz, const float* __restrict__ x,
+                                                                int N, int H, int W, int Cout, double* __restrict__ acc) {
+    constexpr int EPV = TT<T>::EPV;
+    __shared__ float sm[256 * EPV];               // one tap's partials [pixel lane][channel]
+    const int G = Cout / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    float part[9][EPV];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) part[t][e] = 0.f;
+    const int tiles_w = (W + PL - 1) / PL, tiles_h = (H + FIRST_R - 1) / FIRST_R;
+    const int per_img = tiles_w * tiles_h;
+    for (long long tile = blockIdx.x; tile < (long long)per_img * N; tile += gridDim.x) {
+        const int n = (int)(tile / per_img), tt = (int)(tile - (long long)n * per_img);
+        const int th = tt / tiles_w, tw = tt - th * tiles_w;
+        const int h0 = th * FIRST_R, wq = tw * PL + pl;
+        if (!active || wq >= W) continue;
+        const int h1 = min(h0 + FIRST_R, H);
+        const float* xi = x + (long long)n * H * W;
+        const T* di = dz + (long long)n * H * W * Cout;
+        float ra[3], rb[3], rc[3];
+        first_row3(xi, h0 - 1, wq, H, W, ra);
+        first_row3(xi, h0, wq, H, W, rb);
+        for (int h = h0; h < h1; ++h) {
+            first_row3(xi, h + 1, wq, H, W, rc);
+            float g[EPV];
+            Vec16<T>::unpack(*(const uint4*)(di + ((long long)h * W + wq) * Cout + cg * EPV), g);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    part[k][e] = fmaf(g[e], ra[k], part[k][e]);
+                    part[3 + k][e] = fmaf(g[e], rb[k], part[3 + k][e]);
+                    part[6 + k][e] = fmaf(g[e], rc[k], part[6 + k][e]);
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+        }
+    }
+    // reduce over pixel lanes one tap at a time through LDS [pl][cg][EPV] (as the generic kernel)
+    const int per = G * EPV;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) sm[(pl * G + cg) * EPV + e] = part[t][e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += 256) {
+            float s = 0.f;
+            for (int p = 0; p < PL; ++p) s += sm[p * per + i];
+            atomicAdd(&acc[(size_t)i * 9 + t], (double)s);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void first_wgrad_store_kernel(const double* __restrict__ acc, float* __restrict__ dw, int Cout, int Cin, int ci, int NT) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Cout * NT) return;
@@ -351,7 +492,11 @@ extern "C" int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, co
     const int gx = rows / N;
 #define LF(T, A, B) hipLaunchKernelGGL((conv_first_fwd_kernel<T, A, B>), dim3(gx, N), dim3(256), lds, s, x, w, bias, (T*)z, stats, N, H, W, Cin, Cout)
 #define LFD(A, B) do { if (dtype == UNET_BF16) LF(__bf16, A, B); else LF(float, A, B); } while (0)
-    if (kh == 3 && kw == 3) LFD(3, 3);
+    if (kh == 3 && kw == 3 && Cin == 1) {
+        if (dtype == UNET_BF16) hipLaunchKernelGGL((conv_first1_fwd_kernel<__bf16>), dim3(gx, N), dim3(256), 0, s, x, w, bias, (__bf16*)z, stats, H, W, Cout);
+        else hipLaunchKernelGGL((conv_first1_fwd_kernel<float>), dim3(gx, N), dim3(256), 0, s, x, w, bias, (float*)z, stats, H, W, Cout);
+    }
+    else if (kh == 3 && kw == 3) LFD(3, 3);
     else if (kh == 5 && kw == 5) LFD(5, 5);
     else if (kh == 3 && kw == 1) LFD(3, 1);
     else if (kh == 1 && kw == 3) LFD(1, 3);
@@ -379,7 +524,11 @@ extern "C" int unet_conv_first_wgrad(int dtype, int kh, int kw, const void* dz, 
         if (hipMemsetAsync(acc_ws, 0, sizeof(double) * Cout * NT, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
 #define LW(T, A, B) hipLaunchKernelGGL((conv_first_wgrad_kernel<T, A, B>), dim3(grid), dim3(256), lds, s, (const T*)dz, x, N, H, W, Cin, ci, Cout, acc_ws)
 #define LWD(A, B) do { if (dtype == UNET_BF16) LW(__bf16, A, B); else LW(float, A, B); } while (0)
-        if (kh == 3 && kw == 3) LWD(3, 3);
+        if (kh == 3 && kw == 3 && Cin == 1) {
+            if (dtype == UNET_BF16) hipLaunchKernelGGL((conv_first1_wgrad_kernel<__bf16>), dim3(grid), dim3(256), 0, s, (const __bf16*)dz, x, N, H, W, Cout, acc_ws);
+            else hipLaunchKernelGGL((conv_first1_wgrad_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dz, x, N, H, W, Cout, acc_ws);
+        }
+        else if (kh == 3 && kw == 3) LWD(3, 3);
         else if (kh == 3 && kw == 1) LWD(3, 1);
         else if (kh == 1 && kw == 3) LWD(1, 3);
         else if (kh == 5 && kw == 1) LWD(5, 1);
