@@ -140,6 +140,18 @@ int unet_dice_ce_fwd(const float* logits, const long long* target, int N, int C,
 int unet_dice_ce_bwd(const float* logits, const long long* target, int N, int C, long long HW,
                      float ce_weight, float dice_weight, long long ignore_index, int ce_only, double eps,
                      const double* acc_ws, const float* grad_out, float* dlogits, void* stream);
+/* ---- device input pipeline --------------------------------------------------------------------
+ * CT_NpyDataset.__getitem__ (data/ct_dataset.py:25-84) for a batch of N <= 64 raw slices of one size:
+ * lung window (:32-33), bilinear / nearest safety resize to SxS (:40-47), hflip / vflip (:52-59),
+ * rotation (:62-66, torchvision TF.rotate: affine grid + grid_sample, zeros outside), mask > 0 (:82).
+ * image fp32 [N,H0,W0], mask uint8 [N,H0,W0] -> out_image fp32 [N,1,S,S], out_mask int64 [N,S,S].
+ * flags[n] (HOST): 1 hflip | 2 vflip | 4 rotate; theta (HOST, N x 6 floats): the rescaled inverse affine
+ * matrix of torchvision's _gen_affine_grid as [T00 T01 T10 T11 T20 T21], grid = [x y 1] * T.
+ * tmp_image / tmp_mask (N*S*S each) are needed only when (H0,W0) != (S,S). */
+int unet_ct_preprocess(const float* image, const uint8_t* mask, int N, int H0, int W0, int S,
+                       const int* flags, const float* theta, float* tmp_image, uint8_t* tmp_mask,
+                       float* out_image, long long* out_mask, void* stream);
+
 /* logits.argmax(1) -- trainer.py:119, utils/eval_utils.py:103 */
 int unet_argmax(const float* logits, long long* out, int N, int C, long long HW, void* stream);
 /* entropy-weighted two-model fusion per pixel -- eval_ensemble.py:9-11,77-99 */
