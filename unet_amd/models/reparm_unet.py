@@ -158,6 +158,28 @@ class ReparamUNet(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
 
+    def make_deploy_skeleton(self):
+        """Turn an un-deployed model into the deploy-mode STRUCTURE (one zero-initialised `mergedConv` per
+        MultiConvBlock, branches removed) without folding, so that a deployed checkpoint -- keys
+        `...reparam_conv.{0,2}.mergedConv.{weight,bias}`, the reference's layout after switch_to_deploy
+        (models/reparm_unet.py:139-144) -- can be loaded.  load_state_dict() calls it when it sees such keys."""
+        for module in list(self.modules()):
+            if isinstance(module, MultiConvBlock) and not module.mergedFlag:
+                max_k = module.kernel_sizes[-1]
+                ref = next(module.parameters())
+                module.mergedConv = getConv2D(module.in_channels, module.out_channels, (max_k, max_k), module.stride,
+                                              [max_k // 2, max_k // 2], bias=True).to(device=ref.device, dtype=ref.dtype)
+                module.mergedFlag = True
+                delattr(module, "conv_list")
+        self._engine._packed.clear()
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        deployed_keys = any(".mergedConv." in k for k in state_dict)
+        has_branches = any(isinstance(m, MultiConvBlock) and not m.mergedFlag for m in self.modules())
+        if deployed_keys and has_branches:
+            self.make_deploy_skeleton()
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
     def switch_to_deploy(self):
         """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels)."""
         print("[ReparamUNet] Switching to deploy mode (fusing kernels)...")
