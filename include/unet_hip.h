@@ -82,6 +82,13 @@ int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, i
 int unet_pack_weights_multi(int dtype, int nt, const int* modes, const void* const* src, void* const* dst,
                             const int* O, const int* I, const int* ntaps, void* stream);
 
+/* Inference: fold BatchNorm2d running statistics into the preceding conv of DoubleConv (models/unet.py:9-16):
+ * w_out = w * s, b_out = beta + (bias - mean) * s, s = gamma / sqrt(var + eps) -- mergeBN's algebra
+ * (models/reparm_unet.py:28-31) for the plain UNet.  O = Cout, per = Cin*kh*kw.  bias may be NULL. */
+int unet_fold_bn_conv(const float* w, const float* bias, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, float eps, int O, int per,
+                      float* w_out, float* b_out, void* stream);
+
 /* ---- optimizer tail of step_batch ------------------------------------------------------------
  * utils/train_step.py:56-63 (scaler.unscale_ -> clip_grad_norm_ -> optimizer.step) with the AdamW of
  * utils/builders.py:143-146, as multi-tensor kernels over fp32 tensors.  The tensor lists are HOST

@@ -205,3 +205,41 @@ def test_trainer_fit_and_evaluate_smoke(dev):
     vl, score, stats = tr.evaluate(dl, epoch=2)
     assert set(stats) >= {"val_loss", "acc_pixel", "dice_macro", "dice_class_1", "mae"}
     assert score == stats["dice_class_1"]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_eval_bn_fold_matches_unfolded(dev, dtype):
+    """Inference folds BatchNorm into the conv (+ReLU epilogue); it must agree with conv -> BN(eval) -> ReLU, and
+    must follow parameter / running-statistics updates (training step, load_state_dict)."""
+    m, g = build("unet_f8x16x32x64", dev)
+    m.compute_dtype = dtype
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for k, b in m.named_buffers():
+            if k.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+            if k.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+    x = g["x"].to(dev)
+    tol = 1e-5 if dtype == "fp32" else 2e-2
+
+    def both():
+        m.eval()
+        with torch.no_grad():
+            m._engine.fold_bn_eval = True
+            a = m(x).float().cpu()
+            m._engine.fold_bn_eval = False
+            b = m(x).float().cpu()
+            m._engine.fold_bn_eval = True
+        return a, b
+
+    a, b = both()
+    assert rell2(a, b) < tol
+    m.train()                                      # a training forward moves the running statistics under raw pointers
+    m(x)
+    a2, b2 = both()
+    assert rell2(a2, b2) < tol and rell2(a2, a) > 1e-2
+    sd = {k: (v * 1.5 if k.endswith("double_conv.0.weight") else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    a3, b3 = both()
+    assert rell2(a3, b3) < tol and rell2(a3, a2) > 1e-2

@@ -588,6 +588,34 @@ extern "C" int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x,
     return 0;
 }
 
+// Inference-time fold of BatchNorm2d (running statistics) into the conv in front of it, DoubleConv of
+// /root/reference/models/unet.py:9-16: w' = w * s, b' = beta + (b - mean) * s with s = gamma / sqrt(var + eps)
+// -- the algebra of the reference's mergeBN (models/reparm_unet.py:28-31) applied to the plain UNet.
+__global__ void fold_bn_conv_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ rm, const float* __restrict__ rv,
+                                    float eps, int O, int per, float* __restrict__ wo, float* __restrict__ bo) {
+    const size_t total = (size_t)O * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int o = (int)(i / per);
+        const float sc = gamma[o] * (1.0f / sqrtf(rv[o] + eps));
+        wo[i] = w[i] * sc;
+        if (i - (size_t)o * per == 0) bo[o] = beta[o] + ((b != nullptr ? b[o] : 0.f) - rm[o]) * sc;
+    }
+}
+
+extern "C" int unet_fold_bn_conv(const float* w, const float* bias, const float* gamma, const float* beta,
+                                 const float* running_mean, const float* running_var, float eps, int O, int per,
+                                 float* w_out, float* b_out, void* stream) {
+    UNET_CHECK(w && gamma && beta && running_mean && running_var && w_out && b_out, "fold_bn_conv: null argument");
+    UNET_CHECK(O > 0 && per > 0, "fold_bn_conv: bad shape %d x %d", O, per);
+    const size_t total = (size_t)O * per;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fold_bn_conv_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, bias, gamma, beta,
+                       running_mean, running_var, eps, O, per, w_out, b_out);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, int I, int ntaps, void* stream) {
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
     UNET_CHECK(mode >= 0 && mode <= 3, "bad pack mode %d", mode);

@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const bool do_stats = a.stats != nullptr;
         float* red = (float*)(smem + C::OFF_RED);     // [wr][BCO][2]
         const int co_w = cur.cb * BCO + wc * 64;
-        // FAST: the tile lies inside the output, plain store (no accumulate / ReLU), and this wave's 64
+        // FAST: the tile lies inside the output, plain store (no accumulate; ReLU allowed), and this wave's 64
         // channels go to one destination: every store is a wave-uniform base plus one per-lane offset
         constexpr bool fast = !GEN;
         auto epilogue = [&](auto fast_tag) {
@@ -375,6 +375,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // whole cache lines, instead of 64 scattered 8-byte pieces per instruction.
                 // (hs was toggled after the chunk loop: the stage just read is hs ^ 1)
                 char* scr = smem + (hs ^ 1) * C::H_BYTES + wave * 1024;
+                const bool relu_out = (a.flags & 2) != 0;             // deployed / BN-folded inference convs
                 const int wpx = l15, rpx = lane >> 3, rch = lane & 7;
                 const unsigned st_off = (unsigned)(rpx * ld + rch * 8) * 2u;
                 const size_t row_stride = (size_t)a.Wout * ld * 2, half_stride = (size_t)8 * ld * 2;
@@ -384,9 +385,11 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                     for (int ct = 0; ct < 4; ++ct) {
                         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (a.bias != nullptr) bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
+                        float v0 = acc[ct][pg][0] + bv.x, v1 = acc[ct][pg][1] + bv.y, v2 = acc[ct][pg][2] + bv.z, v3 = acc[ct][pg][3] + bv.w;
+                        if (relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                         uint2 pk;
-                        pk.x = Vec16<__bf16>::pk(acc[ct][pg][0] + bv.x, acc[ct][pg][1] + bv.y);
-                        pk.y = Vec16<__bf16>::pk(acc[ct][pg][2] + bv.z, acc[ct][pg][3] + bv.w);
+                        pk.x = Vec16<__bf16>::pk(v0, v1);
+                        pk.y = Vec16<__bf16>::pk(v2, v3);
                         *(uint2*)(scr + (wpx >> 3) * 8192 + (wpx & 7) * 128 + (((ct * 2 + (g >> 1)) ^ (wpx & 7)) << 4) + (g & 1) * 8) = pk;
                     }
                     char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
@@ -498,7 +501,7 @@ int conv2_tiles(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((W
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     const int bco = a.Cout > 64 ? 128 : 64;
     const bool gen = (a.Cin & 31) != 0 || (a.Cout % bco) != 0 || (a.Hout & 15) != 0 || (a.Wout & 31) != 0 ||
-                     (a.flags & 3) != 0 || (a.csplit & 63) != 0;
+                     (a.flags & 1) != 0 || (a.csplit & 63) != 0;
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
     return gen ? launch_conv2<1, true>(a, s) : launch_conv2<1, false>(a, s);
 }

@@ -38,6 +38,9 @@ class UNetEngine:
         self.n_classes = n_classes
         self._ws: Dict[torch.device, Workspace] = {}
         self._packed = {}       # (name, mode, dt) -> (version, tensor)
+        self._folded = {}       # (conv weight name, dt) -> (versions, packed folded weights, folded bias)
+        self._stats_gen = 0     # bumped by every training forward (running statistics change under raw pointers)
+        self.fold_bn_eval = True
 
     # ------------------------------------------------------------------ helpers
     def ws(self, device) -> Workspace:
@@ -55,6 +58,18 @@ class UNetEngine:
         t = ops.pack_weights(p, mode, dt)
         self._packed[key] = (ver, t)
         return t
+
+    def folded(self, wname, bname, bnp, P, B, dt):
+        """Packed conv weights and bias with the eval-mode BatchNorm folded in (inference path)."""
+        ts = [P[wname], P[bname], P[bnp + ".weight"], P[bnp + ".bias"], B[bnp + ".running_mean"], B[bnp + ".running_var"]]
+        ver = tuple((t._version, t.data_ptr()) for t in ts) + (self._stats_gen,)
+        hit = self._folded.get((wname, dt))
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        wf, bf = ops.fold_bn_conv(ts[0], ts[1].detach(), ts[2].detach(), ts[3].detach(), ts[4], ts[5], BN_EPS)
+        wp = ops.pack_weights(wf, 0, dt)
+        self._folded[(wname, dt)] = (ver, wp, bf)
+        return wp, bf
 
     def prepack(self, P, dt):
         """Refresh, in ONE launch, every packed image this engine has used before whose parameter has changed
@@ -83,6 +98,12 @@ class UNetEngine:
         Cout = w.shape[0]
         dev = w.device
         ws = self.ws(dev)
+        if not train and not save and not first and self.fold_bn_eval:
+            # inference: BatchNorm folded into the conv, ReLU in its epilogue -- one pass instead of two
+            wp, bf = self.folded(wname, bname, bnp, P, B, dt)
+            y = yout if yout is not None else ops.dense(xin.N, xin.H, xin.W, Cout, dt, dev)
+            ops.conv_fwd(xin, wp, bf, y, 3, 3, w.shape[1], Cout, relu=True)
+            return y, None
         if first:
             N, H, W_, _ = x_f32.shape
             z = ops.dense(N, H, W_, Cout, dt, dev)
@@ -93,6 +114,7 @@ class UNetEngine:
             rows = ops.conv_fwd(xin, self.packed(wname, w, 0, dt), b.detach(), z, 3, 3, Cin, Cout, stats=train)
         gamma, beta = P[bnp + ".weight"].detach(), P[bnp + ".bias"].detach()
         if train:
+            self._stats_gen += 1
             st = ops.bn_finalize(rows, z.M, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
                                  B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
         else:

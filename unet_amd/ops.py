@@ -105,6 +105,23 @@ def pack_weights(w: torch.Tensor, mode: int, dt: int) -> torch.Tensor:
     return out
 
 
+def fold_bn_conv(w, bias, gamma, beta, running_mean, running_var, eps):
+    """(w', b') of conv followed by eval-mode BatchNorm2d, fp32 on the device."""
+    _need_cuda(w, gamma, beta, running_mean, running_var)
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    O = w.shape[0]
+    for t in (gamma, beta, running_mean, running_var) + ((bias,) if bias is not None else ()):
+        if t.numel() != O or t.dtype != torch.float32 or not t.is_contiguous():
+            raise UNetHipError("fold_bn_conv: per-channel tensors must be contiguous fp32 of length Cout")
+    wo = torch.empty_like(w)
+    bo = torch.empty(O, dtype=torch.float32, device=w.device)
+    check(lib().unet_fold_bn_conv(_p(w), _p(bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps),
+                                  O, w.numel() // O, _p(wo), _p(bo), _stream()), "fold_bn_conv")
+    return wo, bo
+
+
 def pack_weights_multi(items, dt: int):
     """items: [(fp32 weight, mode, destination tensor)] -> every packed image refreshed in one launch per 40."""
     import ctypes
