@@ -231,8 +231,41 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
         };
         // K-step = one tile row of 32 pixels.  Every fragment of row r+1 is requested before the MFMAs of
         // row r (two register sets), so an LDS round trip is covered by a whole row of matrix work.
-        uint4 fa[2][WM], fb[2][NT][WN];
+        uint4 fa[2][WM];
         load_a(0, fa[0]);
+        if constexpr (SH == 1 && KH == 3) {
+            // The x fragment of (row r, tap kh, kw) is halo row r + kh shifted by kw: consecutive rows share two
+            // of their three halo rows.  Keep a ring of four halo rows in registers and read only the new one
+            // per K-step (3 fragments instead of 9: the LDS read traffic of the loop drops from 22 to 10
+            // transposed reads per 18 MFMAs).
+            uint4 hf[4][KW][WN];
+            auto load_h = [&](int row, uint4 (*dst)[WN]) {
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        dst[kw][j] = tr_frag2(img + row * (HWD * REC) + b_lo[kw][j], img + row * (HWD * REC) + b_hi[kw][j]);
+            };
+            load_h(0, hf[0]); load_h(1, hf[1]); load_h(2, hf[2]);
+#pragma unroll
+            for (int r = 0; r < TH; ++r) {
+                if (r + 1 < TH) {
+                    load_a(r + 1, fa[(r + 1) & 1]);
+                    load_h(r + 3, hf[(r + 3) & 3]);
+                }
+                if (more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j)
+                            acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, hf[(r + t2 / KW) & 3][t2 % KW][j]),
+                                acc[t2][i][j], 0, 0, 0);
+            }
+        } else {
+        uint4 fb[2][NT][WN];
 #pragma unroll
         for (int t2 = 0; t2 < NT; ++t2) load_b(0, t2, fb[0][t2]);
 #pragma unroll
@@ -253,6 +286,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
                     for (int j = 0; j < WN; ++j)
                         acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, fb[r & 1][t2][j]), acc[t2][i][j], 0, 0, 0);
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
         __syncthreads();                                    // ... everyone's; and everyone is done reading `cur`
