@@ -114,12 +114,20 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-timer", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the data-parallel path (process group, DataParallel wrap, bucketed all-reduce) "
+                         "even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -131,7 +139,7 @@ def main():
 
     torch.manual_seed(42)
     model = REGISTRY["unet"](in_channels=1, n_classes=2, features=[64, 128, 256, 512]).to(dev).train()
-    if world > 1:
+    if use_dist:
         model = DataParallel(model, device_ids=[local_rank])
     from unet_amd.utils.builders import get_optim          # the reference's builder API (utils/builders.py:128-146)
     opt = get_optim("adamw", [p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
@@ -146,7 +154,7 @@ def main():
     y = (torch.rand(args.batch, args.size, args.size, generator=g) > 0.95).long().to(dev)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -165,7 +173,7 @@ def main():
     if not args.no_conv_timer:
         timer.remove()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
@@ -192,7 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
