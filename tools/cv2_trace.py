@@ -21,7 +21,7 @@ assert L.unet_debug_set_trace(trace.data_ptr()) == 0
 run(); torch.cuda.synchronize()
 L.unet_debug_set_trace(None)
 t = trace.cpu()[:2048].view(2, 1024)[:, :1000].reshape(2, 500, 2)
-names = {1: "phase start", 2: "mfma issued", 3: "dma waited", 4: "barrier passed", 5: "refill issued", 6: "epilogue done", 7: "first half mfma", 8: "late refill"}
+names = {1: "phase start", 2: "mfma issued", 3: "dma waited", 4: "barrier passed", 5: "refill issued", 6: "epilogue done", 7: "first half mfma", 8: "late refill", 9: "epi: first group packed", 10: "epi: half the groups stored"}
 for wv in range(2):
     ev = [(int(a), int(b)) for a, b in t[wv] if int(b) != 0]
     print(f"--- wave {wv*4}: {len(ev)} events; first 40 deltas (cycles @100MHz-tick? see s_memtime):")

@@ -56,6 +56,14 @@ template <> struct Vec16<__bf16> {
     }
 };
 
+// Two floats -> packed bf16 pair (lo in bits 0-15), one instruction; RNE, NaN stays NaN.  Spelled as asm because
+// hipcc otherwise SLP-pairs the conversions of a uint2 the other way round and shuffles halves afterwards.
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 // One 16x16 MFMA K-record step: 64 bytes of K per row (32 bf16 / 16 f32 channels).
 // a: this lane's 16 bytes of A row (lane&15), k-slot (lane>>4); b likewise for B column (lane&15).
 // D[row = 4*(lane>>4)+reg][col = lane&15].

@@ -346,27 +346,43 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             const size_t pix0 = ((size_t)cur.n * a.Hout + cur.h0 + wr * RW) * a.Wout + cur.w0;
             char* ybase = ydst + (pix0 * ld + chan0) * 2;                                // wave-uniform
             if constexpr (FAST) {
-                // pass 1 (forward only): BN partial statistics of acc + bias
-                if (do_stats) {
+                // Lane-derived addresses of the epilogue are recomputed here from an opaque copy of the lane id: left
+                // to itself hipcc hoists them out of the tile loop and then spills them around the main loop.
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int ge = lane_e >> 4, l15e = lane_e & 15;
+                // + bias, in place (one float4 of biases per 16-channel tile; nothing to do for dgrad launches)
+                if (a.bias != nullptr) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
-                        float b4[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (a.bias != nullptr) {
-                            const float4 bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
-                            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+                        const float4 b4 = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * ge) * 4);
+#pragma unroll
+                        for (int pg = 0; pg < NPG; ++pg) {
+                            acc[ct][pg][0] += b4.x; acc[ct][pg][1] += b4.y; acc[ct][pg][2] += b4.z; acc[ct][pg][3] += b4.w;
                         }
+                    }
+                }
+                // pass 1 (forward only): BN partial statistics.  Every lane stores its (sum, sum of squares) pair:
+                // lanes other than the group's first aim at a scratch slot, which is cheaper than sixteen exec-mask
+                // round trips.
+                if (do_stats) {
+                    // one address select per lane; the 16 pairs then go to base + immediate (the scratch slots of
+                    // different lanes overlap, which is fine for values nobody reads, and stay on distinct banks)
+                    char* sbase = l15e == 0 ? (char*)&red[(wr * BCO + wc * 64 + 4 * ge) * 2]
+                                           : smem + (hs ^ 1) * C::H_BYTES + (wave + 16) * 1024 + lane_e * 8;
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int pg = 0; pg < NPG; ++pg)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { const float v = acc[ct][pg][r] + b4[r]; s1[r] += v; s2[r] += v * v; }
+                            for (int r = 0; r < 4; ++r) { const float v = acc[ct][pg][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float t1 = wave_sum16(s1[r]);
-                            const float t2 = wave_sum16(s2[r]);
-                            if (l15 == 0) {
-                                red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 0] = t1;
-                                red[(wr * BCO + wc * 64 + ct * 16 + 4 * g + r) * 2 + 1] = t2;
-                            }
+                            float2 t;
+                            t.x = wave_sum16(s1[r]);
+                            t.y = wave_sum16(s2[r]);
+                            *(float2*)(sbase + (ct * 16 + r) * 8) = t;
                         }
                     }
                 }
@@ -375,31 +391,35 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // whole cache lines, instead of 64 scattered 8-byte pieces per instruction.
                 // (hs was toggled after the chunk loop: the stage just read is hs ^ 1)
                 char* scr = smem + (hs ^ 1) * C::H_BYTES + wave * 1024;
-                const bool relu_out = (a.flags & 2) != 0;             // deployed / BN-folded inference convs
-                const int wpx = l15, rpx = lane >> 3, rch = lane & 7;
+                const int wpx = l15e, rpx = lane_e >> 3, rch = lane_e & 7;
                 const unsigned st_off = (unsigned)(rpx * ld + rch * 8) * 2u;
                 const size_t row_stride = (size_t)a.Wout * ld * 2, half_stride = (size_t)8 * ld * 2;
+                char* wbase = scr + (wpx >> 3) * 8192 + (wpx & 7) * 128 + (ge & 1) * 8;
+                const char* rbase = scr + rpx * 128 + ((rch ^ rpx) << 4);
+                auto pass2 = [&](auto relu_tag) {
+                    constexpr bool RELU = decltype(relu_tag)::value;            // deployed / BN-folded inference convs
 #pragma unroll
-                for (int pg = 0; pg < NPG; ++pg) {
+                    for (int pg = 0; pg < NPG; ++pg) {
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (a.bias != nullptr) bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
-                        float v0 = acc[ct][pg][0] + bv.x, v1 = acc[ct][pg][1] + bv.y, v2 = acc[ct][pg][2] + bv.z, v3 = acc[ct][pg][3] + bv.w;
-                        if (relu_out) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-                        uint2 pk;
-                        pk.x = Vec16<__bf16>::pk(v0, v1);
-                        pk.y = Vec16<__bf16>::pk(v2, v3);
-                        *(uint2*)(scr + (wpx >> 3) * 8192 + (wpx & 7) * 128 + (((ct * 2 + (g >> 1)) ^ (wpx & 7)) << 4) + (g & 1) * 8) = pk;
+                        for (int ct = 0; ct < 4; ++ct) {
+                            float v0 = acc[ct][pg][0], v1 = acc[ct][pg][1], v2 = acc[ct][pg][2], v3 = acc[ct][pg][3];
+                            if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                            uint2 pk;
+                            pk.x = cvt_pk_bf16(v0, v1);
+                            pk.y = cvt_pk_bf16(v2, v3);
+                            *(uint2*)(wbase + (((ct * 2 + (ge >> 1)) ^ (wpx & 7)) << 4)) = pk;
+                        }
+                        if (pg == 0) STAMP(9);
+                        if (pg == NPG / 2) STAMP(10);
+                        char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint4 val = *(const uint4*)(rbase + h * 8192);
+                            *(uint4*)(pp + h * half_stride) = val;
+                        }
                     }
-                    char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int px = h * 8 + rpx;
-                        const uint4 val = *(const uint4*)(scr + h * 8192 + rpx * 128 + ((rch ^ rpx) << 4));
-                        *(uint4*)(pp + h * half_stride) = val;
-                    }
-                }
+                };
+                if (a.flags & 2) pass2(std::true_type{}); else pass2(std::false_type{});
             } else {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
