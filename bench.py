@@ -9,7 +9,7 @@ on synthetic 512x512 CT slices, bf16 compute, per-GPU batch 32 (BASELINE.json co
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the bf16 3x3 implicit-GEMM conv,
 forward + dgrad launches): algorithmic FLOPs of its launches / their durations measured with HIP
-events on the launch stream inside the timed region.  `cpu_baseline` is the CPU oracle (torch fp32
+events on the launch stream inside the timed region (the launches of the last timed step).  `cpu_baseline` is the CPU oracle (torch fp32
 restatement of the reference, pinned to golden vectors) timed on a bounded sample on this host.
 """
 import argparse
@@ -160,13 +160,16 @@ def main():
 
     for i in range(args.warmup):
         step_batch(trainer, x, y, scaler, batch_idx=i + 1)
+    # The per-launch HIP events of the roofline measurement cost ~0.1 ms each in lost launch overlap (3-4 ms over a
+    # step's 35 conv launches), so they bracket the conv launches of the LAST timed step only: still inside the timed
+    # region, but `value` is perturbed by 1/K of that instead of all of it.
     timer = ConvTimer()
-    if not args.no_conv_timer:
-        timer.install()
     sync()
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
+        if i == args.steps - 1 and not args.no_conv_timer:
+            timer.install()
         last = step_batch(trainer, x, y, scaler, batch_idx=i + 1)
     sync()
     dt = time.perf_counter() - t0
