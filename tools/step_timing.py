@@ -21,9 +21,11 @@ x = torch.rand(32, 1, 512, 512, generator=g).to(dev)
 y = (torch.rand(32, 512, 512, generator=g) > 0.95).long().to(dev)
 if nogc:
     gc.disable()
+if "--late-pack" in sys.argv:          # A/B: weights re-packed at the start of the next forward instead
+    model.prepack_weights = None
 ts = []
 for i in range(24):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     step_batch(tr, x, y, sc, batch_idx=i + 1)
     torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
-print("nogc" if nogc else "gc", " ".join(f"{t:.1f}" for t in ts))
+print(" ".join(sys.argv[1:]) or "default", f"mean {sum(ts[4:]) / len(ts[4:]):.2f} |", " ".join(f"{t:.1f}" for t in ts))

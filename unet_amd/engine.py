@@ -150,6 +150,7 @@ class UNetEngine:
             # the reference falls into a bilinear-resize branch here (models/unet.py:56-57); not built
             raise ops.UNetHipError(f"H and W must be divisible by {1 << L} (got {H}x{W})")
         dev = x.device
+        self._last_dt = dt
         self.prepack(P, dt)
         x = x.detach()
         if x.dtype != torch.float32:

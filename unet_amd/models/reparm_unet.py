@@ -158,6 +158,13 @@ class ReparamUNet(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
 
+    def prepack_weights(self):
+        """Refresh the packed compute-dtype weight images now (step_batch calls this right after the optimizer step,
+        so the work is queued behind it instead of sitting in front of the next forward)."""
+        dt = getattr(self._engine, "_last_dt", None)
+        if dt is not None:
+            self._engine.prepack(dict(self.named_parameters()), dt)
+
     def make_deploy_skeleton(self):
         """Turn an un-deployed model into the deploy-mode STRUCTURE (one zero-initialised `mergedConv` per
         MultiConvBlock, branches removed) without folding, so that a deployed checkpoint -- keys

@@ -106,6 +106,13 @@ class UNet(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
 
+    def prepack_weights(self):
+        """Refresh the packed compute-dtype weight images now (step_batch calls this right after the optimizer step,
+        so the work is queued behind it instead of sitting in front of the next forward)."""
+        dt = getattr(self._engine, "_last_dt", None)
+        if dt is not None:
+            self._engine.prepack(dict(self.named_parameters()), dt)
+
 
 def build_unet(**kwargs):
     return UNet(**kwargs)

@@ -57,6 +57,10 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
             torch.nn.utils.clip_grad_norm_(trainer.model.parameters(), trainer.grad_clip)
         scaler.step(trainer.optimizer)
     scaler.update()
+    inner = getattr(trainer.model, "module", trainer.model)
+    prepack = getattr(inner, "prepack_weights", None)
+    if prepack is not None:        # re-pack the updated weights now, behind the optimizer kernels, not before the next forward
+        prepack()
 
     step_idx = int(getattr(trainer, "_global_step", 0)) + 1
     setattr(trainer, "_global_step", step_idx)
