@@ -125,6 +125,14 @@ int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, con
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* dbias,
                      float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
+/* The same with dy = dskip + unpool(dpool, code): the backward of MaxPool2d(2,2) (models/unet.py:47) and the
+ * skip-connection add evaluated inside both passes, so the gradient of an encoder level's output is never stored.
+ * dpool [N,H/2,W/2,C] dense, code from unet_maxpool2x2_fwd, dskip a channel slice (lds, soff) of [N,H,W,*]. */
+int unet_bn_relu_bwd_pool(int dtype, int relu, const void* dpool, const uint8_t* code, const void* dskip, int lds, int soff,
+                          const void* z, int ldz, int zoff, void* dz, int ldo, int ooff,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          float* dgamma, float* dbeta, float* dbias, float* c1c2_ws, double* acc_ws,
+                          int N, int H, int W, int C, void* stream);
 int unet_relu_bwd(int dtype, const void* dy, int ldd, int doff, const void* y, int ldy, int yoff,
                   void* dz, int ldo, int ooff, long long M, int C, void* stream);
 int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, long long M, int C, float* out, int accumulate,

@@ -313,6 +313,45 @@ def test_maxpool_indices_bit_exact(dev, dt):
     close(from_act(dx), dref, dt, "maxpool bwd")
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("geom", [(2, 16, 12, 20), (1, 64, 8, 8), (3, 24, 6, 10), (1, 512, 4, 6)])
+def test_bn_relu_bwd_with_fused_unpool(dev, dt, geom):
+    """BN+ReLU backward fed by (pooled gradient, argmax code, skip gradient) against torch autograd through
+    max_pool2d + skip add + batch_norm + relu, and against the two-kernel path (unpool, then BN backward)."""
+    ops = ops_mod()
+    N, C, H, W = geom
+    z = q(rnd((N, C, H, W), 31) * 1.5 + 0.3, dt)
+    gamma, beta = rnd((C,), 32).abs() + 0.5, rnd((C,), 33)
+    z.requires_grad_(True); gamma.requires_grad_(True); beta.requires_grad_(True)
+    y = F.relu(F.batch_norm(z, None, None, gamma, beta, True, 0.1, 1e-5))
+    yq = q(y.detach(), dt)                            # what the pool kernel reads
+    dpool = q(rnd((N, C, H // 2, W // 2), 34), dt)
+    dskip = q(rnd((N, C, H, W), 35), dt)
+    pooled, idx = F.max_pool2d(yq, 2, 2, return_indices=True)
+    dy_ref = torch.zeros(N, C, H * W).scatter_add_(2, idx.view(N, C, -1), dpool.view(N, C, -1)).view(N, C, H, W) + dskip
+    y.backward(dy_ref)
+    ws = ops.Workspace(dev)
+    za = to_act(z.detach(), dt, dev)
+    zz = z.detach().double()
+    rows = torch.stack([zz.sum((2, 3)), (zz * zz).sum((2, 3))], -1).float().to(dev).contiguous()
+    st = ops.bn_finalize(rows, N * H * W, gamma.detach().to(dev), beta.detach().to(dev), None, None, None, 0.1, 1e-5, ws)
+    _, code = ops.maxpool_fwd(to_act(yq, dt, dev))
+    assert torch.equal(ops.pool_indices_int64(code, W).cpu(), idx)
+    src = ops.PoolGrad(to_act(dpool, dt, dev), code, to_act(dskip, dt, dev, ld=C + 8, off=8))
+    dz = ops.dense(N, H, W, C, dt, dev)
+    dg, db, dbias = ops.bn_relu_bwd_pool(src, za, dz, st, ws)
+    close(dg.cpu(), gamma.grad, dt, "dgamma", f32_out=True)
+    close(db.cpu(), beta.grad, dt, "dbeta", f32_out=True)
+    close(from_act(dz), z.grad, dt, "bn dz")
+    # two-kernel path on the same inputs: identical in fp32 (in bf16 it rounds the stored dy once more)
+    dy2 = ops.maxpool_bwd(src.dpool, code, src.dskip)
+    dz2 = ops.dense(N, H, W, C, dt, dev)
+    dg2, db2, dbias2 = ops.bn_relu_bwd(dy2, za, dz2, st, ws)
+    if dt == 0:
+        torch.testing.assert_close(dz.buf, dz2.buf, rtol=1e-6, atol=1e-7)      # fp64 atomics: summation order varies
+        torch.testing.assert_close(dg, dg2, rtol=1e-6, atol=1e-7)
+
+
 def load(name):
     z = np.load(os.path.join(G, name + ".npz"))
     return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}

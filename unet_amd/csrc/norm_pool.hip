@@ -138,9 +138,43 @@ __device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const floa
     }
 }
 
+// Where BN backward takes dy from.  Plain: a stored tensor.  POOL: the gradient of an encoder level's output,
+// dy[n,h,w,c] = dskip[n,h,w,c] + (code[n,h/2,w/2,c] == 2(h&1)+(w&1) ? dpool[n,h/2,w/2,c] : 0), i.e. the backward of
+// MaxPool2d(2,2) plus the skip-connection gradient (models/unet.py:47,59) evaluated on the fly in fp32, so that dy is
+// never written and read back (the two passes read 2.75 B/element more, the un-pool kernel's 4.75 B/element go away).
+struct PoolSrc { const void* dpool; const uint8_t* code; int H, W; };
+
+template <typename T, bool POOL>
+__device__ __forceinline__ void load_dy(const T* __restrict__ dy, int ldd, int doff, const PoolSrc& ps, long long p, int cg, int C,
+                                        float (&fd)[TT<T>::EPV]) {
+    constexpr int EPV = TT<T>::EPV;
+    Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + cg * EPV), fd);
+    if (POOL) {
+        const int pi = (int)p;
+        const int w = pi % ps.W, t = pi / ps.W, h = t % ps.H, n = t / ps.H;
+        const long long o = (((long long)n * (ps.H >> 1) + (h >> 1)) * (ps.W >> 1) + (w >> 1)) * C + cg * EPV;
+        const unsigned k = (unsigned)(2 * (h & 1) + (w & 1));
+        float g[EPV];
+        Vec16<T>::unpack(*(const uint4*)((const T*)ps.dpool + o), g);
+        if (EPV == 8) {
+            const uint2 pk = *(const uint2*)(ps.code + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (((pk.x >> (8 * e)) & 0xff) == k) fd[e] += g[e];
+                if (((pk.y >> (8 * e)) & 0xff) == k) fd[(4 + e) % EPV] += g[(4 + e) % EPV];
+            }
+        } else {
+            const uint32_t pk = *(const uint32_t*)(ps.code + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (((pk >> (8 * e)) & 0xff) == k) fd[e] += g[e];
+        }
+    }
+}
+
 // BN+ReLU backward, pass 1: S1 = sum dy', S2 = sum dy' * xhat with dy' = dy * [z*scale+shift > 0]
-template <typename T, bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, int ldd, int doff,
+template <typename T, bool RELU, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(PoolSrc ps, const T* __restrict__ dy, int ldd, int doff,
                                                             const T* __restrict__ z, int ldz, int zoff,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -160,7 +194,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
             float fz[EPV], fd[EPV];
             Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
-            Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + m.cg * EPV), fd);
+            load_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C, fd);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
@@ -187,8 +221,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, double co
 
 // pass 2: dz = scale_g * (dy' - c1 - xhat*c2) with scale_g = gamma*invstd (= forward scale);
 // also accumulates sum(dz) per channel (the bias gradient of the conv in front of the BN).
-template <typename T, bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, int ldd, int doff,
+template <typename T, bool RELU, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* __restrict__ dy, int ldd, int doff,
                                                            const T* __restrict__ z, int ldz, int zoff,
                                                            T* __restrict__ dz, int ldo, int ooff,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -210,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
             float fz[EPV], fd[EPV];
             Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
-            Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + m.cg * EPV), fd);
+            load_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C, fd);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
@@ -413,12 +447,12 @@ extern "C" int unet_affine_act(int dtype, int relu, const void* z, int ldz, int 
     return 0;
 }
 
-extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
-                                void* dz, int ldo, int ooff,
-                                const float* scale, const float* shift, const float* mean, const float* invstd,
-                                float* dgamma, float* dbeta, float* dbias /* nullable */,
-                                float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
-                                long long M, int C, void* stream) {
+template <bool POOL>
+static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                            void* dz, int ldo, int ooff,
+                            const float* scale, const float* shift, const float* mean, const float* invstd,
+                            float* dgamma, float* dbeta, float* dbias, float* c1c2_ws, double* acc_ws,
+                            long long M, int C, void* stream) {
     if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
     UNET_CHECK(ldd % 8 == 0 && doff % 8 == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0,
                "bn_relu_bwd: strides/offsets must be multiples of 8");
@@ -429,8 +463,8 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
     const size_t lds1 = (size_t)256 * 2 * epv * sizeof(float), lds2 = (size_t)256 * epv * sizeof(float);
     float* c1 = c1c2_ws; float* c2 = c1c2_ws + C;
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
-#define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R>), dim3(grid), dim3(256), lds1, s, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
-#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R>), dim3(grid), dim3(256), lds2, s, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, c1, c2, M, C, dbacc)
+#define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
+#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, c1, c2, M, C, dbacc)
     if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
     else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
     UNET_LAUNCH_CHECK();
@@ -446,6 +480,29 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
         UNET_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                                void* dz, int ldo, int ooff,
+                                const float* scale, const float* shift, const float* mean, const float* invstd,
+                                float* dgamma, float* dbeta, float* dbias /* nullable */,
+                                float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
+                                long long M, int C, void* stream) {
+    return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
+                                   scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
+}
+
+extern "C" int unet_bn_relu_bwd_pool(int dtype, int relu, const void* dpool, const uint8_t* code, const void* dskip, int lds, int soff,
+                                     const void* z, int ldz, int zoff, void* dz, int ldo, int ooff,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     float* dgamma, float* dbeta, float* dbias /* nullable */,
+                                     float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
+                                     int N, int H, int W, int C, void* stream) {
+    UNET_CHECK(dpool && code && dskip, "bn_relu_bwd_pool: null argument");
+    UNET_CHECK(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bn_relu_bwd_pool: H and W must be even (got %dx%d)", H, W);
+    UNET_CHECK((long long)N * H * W < 0x7fffffffLL, "bn_relu_bwd_pool: too many pixels");
+    return bn_relu_bwd_impl<true>(PoolSrc{dpool, code, H, W}, dtype, relu, dskip, lds, soff, z, ldz, zoff, dz, ldo, ooff,
+                                  scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, (long long)N * H * W, C, stream);
 }
 
 extern "C" int unet_relu_bwd(int dtype, const void* dy, int ldd, int doff, const void* y, int ldy, int yoff,

@@ -41,6 +41,7 @@ class UNetEngine:
         self._folded = {}       # (conv weight name, dt) -> (versions, packed folded weights, folded bias)
         self._stats_gen = 0     # bumped by every training forward (running statistics change under raw pointers)
         self.fold_bn_eval = True
+        self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
 
     # ------------------------------------------------------------------ helpers
     def ws(self, device) -> Workspace:
@@ -203,12 +204,15 @@ class UNetEngine:
                   split_f: int = 0):
         """Backward of one DoubleConv.  Returns dx (Act), or (dskip, dup) when split_f > 0."""
         r1, r2 = sv.blocks[prefix]
-        dev = dy.buf.device
+        dev = r2.z.buf.device
         ws = self.ws(dev)
         # second conv
         z2 = r2.z
         dz2 = ops.dense(z2.N, z2.H, z2.W, z2.C, dt, dev)
-        dg, db_, dbias = ops.bn_relu_bwd(dy, z2, dz2, r2.st, ws)
+        if isinstance(dy, ops.PoolGrad):      # encoder level: un-pool + skip add happen inside the BN backward passes
+            dg, db_, dbias = ops.bn_relu_bwd_pool(dy, z2, dz2, r2.st, ws)
+        else:
+            dg, db_, dbias = ops.bn_relu_bwd(dy, z2, dz2, r2.st, ws)
         grads[r2.bnp + ".weight"], grads[r2.bnp + ".bias"], grads[r2.bname] = dg, db_, dbias
         w2 = P[r2.wname]
         grads[r2.wname] = ops.conv_wgrad(dz2, r2.xin, 3, 3, ws)[0].view_as(w2)
@@ -283,7 +287,10 @@ class UNetEngine:
         dcur = self.block_bwd(P, sv, "bottleneck", dcur, grads, dt)
         emit(self.block_param_names("bottleneck"))
         for i in reversed(range(L)):
-            dy2 = ops.maxpool_bwd(dcur, sv.codes[i], dskips[i])
+            if self.fused_pool_bwd:
+                dy2 = ops.PoolGrad(dcur, sv.codes[i], dskips[i])
+            else:
+                dy2 = ops.maxpool_bwd(dcur, sv.codes[i], dskips[i])
             dskips[i] = None
             dcur = self.block_bwd(P, sv, f"downs.{i}", dy2, grads, dt, need_dx=(i > 0))
             emit(self.block_param_names(f"downs.{i}"))

@@ -409,6 +409,39 @@ def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True,
     return g[0], g[1], (g[2] if want_dbias else None)
 
 
+@dataclass
+class PoolGrad:
+    """dy of an encoder level's output, not materialised: dskip + unpool(dpool, code)."""
+    dpool: "Act"
+    code: torch.Tensor
+    dskip: "Act"
+
+
+def bn_relu_bwd_pool(src: PoolGrad, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True, want_dbias=True):
+    """bn_relu_bwd with dy = src.dskip + unpool(src.dpool, src.code) evaluated inside the two passes."""
+    dp, code, dskip = src.dpool, src.code, src.dskip
+    dp.check(); dskip.check(); z.check(); dz.check()
+    C = z.C
+    N, H, W = z.N, z.H, z.W
+    if dp.off != 0 or dp.ld != dp.C or (dp.N, dp.H, dp.W, dp.C) != (N, H // 2, W // 2, C) or H % 2 or W % 2:
+        raise UNetHipError("bn_relu_bwd_pool: pooled gradient must be dense [N,H/2,W/2,C]")
+    if tuple(code.shape) != (N, H // 2, W // 2, C) or code.dtype != torch.uint8 or not code.is_contiguous():
+        raise UNetHipError("bn_relu_bwd_pool: code shape mismatch")
+    if (dskip.N, dskip.H, dskip.W, dskip.C) != (N, H, W, C) or (dz.N, dz.H, dz.W, dz.C) != (N, H, W, C):
+        raise UNetHipError("bn_relu_bwd_pool: shape mismatch")
+    if not (dp.dt == dskip.dt == z.dt == dz.dt):
+        raise UNetHipError("bn_relu_bwd_pool: dtype mismatch")
+    if 3 * C > ws.acc.numel() or 2 * C > ws.c1c2.numel():
+        raise UNetHipError("bn_relu_bwd_pool: workspace too small")
+    g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
+    check(lib().unet_bn_relu_bwd_pool(z.dt, 1 if relu else 0, _p(dp.buf), _p(code), _p(dskip.buf), dskip.ld, dskip.off,
+                                      _p(z.buf), z.ld, z.off, _p(dz.buf), dz.ld, dz.off,
+                                      _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                      _p(g[0]), _p(g[1]), _p(g[2]) if want_dbias else None, _p(ws.c1c2), _p(ws.acc),
+                                      N, H, W, C, _stream()), "bn_relu_bwd_pool")
+    return g[0], g[1], (g[2] if want_dbias else None)
+
+
 def relu_bwd(dy: Act, y: Act, dz: Act):
     dy.check(); y.check(); dz.check()
     check(lib().unet_relu_bwd(y.dt, _p(dy.buf), dy.ld, dy.off, _p(y.buf), y.ld, y.off, _p(dz.buf), dz.ld, dz.off,
