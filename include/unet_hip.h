@@ -119,6 +119,11 @@ int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const floa
 /* y = act(z*scale + shift) */
 int unet_affine_act(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
                     const float* scale, const float* shift, long long M, int C, void* stream);
+/* affine_act and MaxPool2d(2,2) of its result in one pass (models/unet.py:45-47): y, pooled [N,H/2,W/2,C] and
+ * code are bit-identical to unet_affine_act followed by unet_maxpool2x2_fwd; y is not read back. */
+int unet_affine_act_pool(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
+                         const float* scale, const float* shift, void* pooled, uint8_t* code,
+                         int N, int H, int W, int C, void* stream);
 /* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z */
 int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
                      void* dz, int ldo, int ooff,

@@ -314,6 +314,25 @@ def test_maxpool_indices_bit_exact(dev, dt):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("geom", [(2, 16, 12, 20), (1, 64, 8, 8), (3, 24, 6, 10), (1, 1024, 2, 4)])
+def test_affine_act_pool_bit_identical_to_two_kernels(dev, dt, geom):
+    ops = ops_mod()
+    N, C, H, W = geom
+    z = q(rnd((N, C, H, W), 41) * 1.5, dt)
+    z[0, 0, 0:2, 0:2] = -3.0                             # an all-zero window after ReLU: ties
+    z[0, 1, 0, 1] = float("nan")
+    st = ops.BNState(rnd((C,), 42).abs().to(dev) + 0.5, rnd((C,), 43).to(dev))
+    za = to_act(z, dt, dev, ld=C + 8, off=8)
+    y1 = ops.Act(torch.zeros((N, H, W, 2 * C), dtype=ops.torch_dtype(dt), device=dev), 0, C)
+    y2 = ops.Act(torch.zeros((N, H, W, 2 * C), dtype=ops.torch_dtype(dt), device=dev), 0, C)
+    ops.affine_act(za, y1, st)
+    p1, c1 = ops.maxpool_fwd(y1)
+    p2, c2 = ops.affine_act_pool(za, y2, st)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
+    assert same(y1.buf, y2.buf) and same(p1.buf, p2.buf) and torch.equal(c1, c2)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("geom", [(2, 16, 12, 20), (1, 64, 8, 8), (3, 24, 6, 10), (1, 512, 4, 6)])
 def test_bn_relu_bwd_with_fused_unpool(dev, dt, geom):
     """BN+ReLU backward fed by (pooled gradient, argmax code, skip gradient) against torch autograd through

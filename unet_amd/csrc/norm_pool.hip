@@ -349,6 +349,62 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     }
 }
 
+// y = relu(z*scale + shift) AND its 2x2 max-pool in one pass (encoder levels, models/unet.py:45-47): the pool
+// compares the values as stored (rounded to T), with the rule of maxpool_fwd_kernel, so y, pooled and code are
+// exactly what affine_act followed by maxpool2x2_fwd produce; y is not read back.
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void affine_act_pool_kernel(const T* __restrict__ z, int ldz, int zoff,
+                                                              T* __restrict__ y, int ldy, int yoff,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              T* __restrict__ pooled, uint8_t* __restrict__ code,
+                                                              int N, int H, int W, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV, Ho = H >> 1, Wo = W >> 1;
+    const long long total = (long long)N * Ho * Wo * G;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+        const int cg = (int)(v % G);
+        long long p = v / G;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float sc[EPV], sh[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { sc[e] = scale[cg * EPV + e]; sh[e] = shift[cg * EPV + e]; }
+        const long long pix0 = ((long long)n * H + 2 * ho) * W + 2 * wo;
+        float best[EPV];
+        unsigned cd[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { best[e] = -INFINITY; cd[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long pix = pix0 + (long long)(k >> 1) * W + (k & 1);
+            float f[EPV];
+            Vec16<T>::unpack(*(const uint4*)(z + pix * ldz + zoff + cg * EPV), f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                f[e] = fmaf(f[e], sc[e], sh[e]);
+                if (RELU) f[e] = fmaxf(f[e], 0.f);
+            }
+            const uint4 o = Vec16<T>::pack(f);
+            *(uint4*)(y + pix * ldy + yoff + cg * EPV) = o;
+            Vec16<T>::unpack(o, f);                       // the pool sees what was stored
+#pragma unroll
+            for (int e = 0; e < EPV; ++e)
+                if (f[e] > best[e] || f[e] != f[e]) { best[e] = f[e]; cd[e] = k; }
+        }
+        const long long o = (((long long)n * Ho + ho) * Wo + wo) * C + cg * EPV;
+        *(uint4*)(pooled + o) = Vec16<T>::pack(best);
+        if (EPV == 8) {
+            uint2 pk;
+            pk.x = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+            pk.y = cd[4 % EPV] | (cd[5 % EPV] << 8) | (cd[6 % EPV] << 16) | (cd[7 % EPV] << 24);
+            *(uint2*)(code + o) = pk;
+        } else {
+            *(uint32_t*)(code + o) = cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
+        }
+    }
+}
+
 // dx[n,2ho+dh,2wo+dw,c] = (skip ? dskip[...] : 0) + (code == 2dh+dw ? dy[n,ho,wo,c] : 0)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ code,
@@ -443,6 +499,24 @@ extern "C" int unet_affine_act(int dtype, int relu, const void* z, int ldz, int 
     if (dtype == UNET_BF16) { if (relu) LAUNCH_AA(__bf16, true); else LAUNCH_AA(__bf16, false); }
     else { if (relu) LAUNCH_AA(float, true); else LAUNCH_AA(float, false); }
 #undef LAUNCH_AA
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_affine_act_pool(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
+                                    const float* scale, const float* shift, void* pooled, uint8_t* code,
+                                    int N, int H, int W, int C, void* stream) {
+    if (chan_check(dtype, C, "affine_act_pool")) return -1;
+    UNET_CHECK(ldz % 8 == 0 && zoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0, "affine_act_pool: strides/offsets must be multiples of 8");
+    UNET_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0 && N > 0, "affine_act_pool: H and W must be even (got %dx%d)", H, W);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / epv);
+    const int grid = grid_for(total, 256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_AP(T, R) hipLaunchKernelGGL((affine_act_pool_kernel<T, R>), dim3(grid), dim3(256), 0, s, (const T*)z, ldz, zoff, (T*)y, ldy, yoff, scale, shift, (T*)pooled, code, N, H, W, C)
+    if (dtype == UNET_BF16) { if (relu) LAUNCH_AP(__bf16, true); else LAUNCH_AP(__bf16, false); }
+    else { if (relu) LAUNCH_AP(float, true); else LAUNCH_AP(float, false); }
+#undef LAUNCH_AP
     UNET_LAUNCH_CHECK();
     return 0;
 }

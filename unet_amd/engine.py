@@ -42,6 +42,8 @@ class UNetEngine:
         self._stats_gen = 0     # bumped by every training forward (running statistics change under raw pointers)
         self.fold_bn_eval = True
         self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
+        self.fused_pool_fwd = True   # UNet: max-pool fused into the BN+ReLU pass of the level's second conv
+        self._pooled = None
 
     # ------------------------------------------------------------------ helpers
     def ws(self, device) -> Workspace:
@@ -91,7 +93,8 @@ class UNetEngine:
                 self._packed[key] = ((p._version, p.data_ptr()), t)
 
     # ------------------------------------------------------------------ forward
-    def _conv_bn_relu(self, P, B, prefix, idx, xin, yout: Optional[Act], dt, train, save, first=False, x_f32=None):
+    def _conv_bn_relu(self, P, B, prefix, idx, xin, yout: Optional[Act], dt, train, save, first=False, x_f32=None,
+                      pool=False):
         """conv3x3(+bias) -> BN -> ReLU.  Returns (y Act, saved record)."""
         wname, bname = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx}.bias"
         bnp = f"{prefix}.double_conv.{idx + 1}"
@@ -104,6 +107,7 @@ class UNetEngine:
             wp, bf = self.folded(wname, bname, bnp, P, B, dt)
             y = yout if yout is not None else ops.dense(xin.N, xin.H, xin.W, Cout, dt, dev)
             ops.conv_fwd(xin, wp, bf, y, 3, 3, w.shape[1], Cout, relu=True)
+            self._pooled = ops.maxpool_fwd(y) if pool else None
             return y, None
         if first:
             N, H, W_, _ = x_f32.shape
@@ -121,7 +125,10 @@ class UNetEngine:
         else:
             st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS)
         y = yout if yout is not None else ops.dense(z.N, z.H, z.W, Cout, dt, dev)
-        ops.affine_act(z, y, st, relu=True)
+        if pool:        # encoder level: the 2x2 max-pool rides on the BN+ReLU pass
+            self._pooled = ops.affine_act_pool(z, y, st, relu=True)
+        else:
+            ops.affine_act(z, y, st, relu=True)
         rec = None
         if save:
             rec = _Saved()
@@ -129,10 +136,11 @@ class UNetEngine:
             rec.wname, rec.bname, rec.bnp = wname, bname, bnp
         return y, rec
 
-    def block_fwd(self, P, B, prefix, xin, yout, dt, train, save, x_f32=None):
-        """One DoubleConv (models/unet.py:9-16).  Returns (output Act, saved record)."""
+    def block_fwd(self, P, B, prefix, xin, yout, dt, train, save, x_f32=None, pool=False):
+        """One DoubleConv (models/unet.py:9-16).  Returns (output Act, saved record); with pool=True the 2x2
+        max-pool of the output (pooled Act, code) is left in self._pooled."""
         y1, r1 = self._conv_bn_relu(P, B, prefix, 0, xin, None, dt, train, save, first=x_f32 is not None, x_f32=x_f32)
-        y2, r2 = self._conv_bn_relu(P, B, prefix, 3, y1, yout, dt, train, save)
+        y2, r2 = self._conv_bn_relu(P, B, prefix, 3, y1, yout, dt, train, save, pool=pool)
         return y2, ((r1, r2) if save else None)
 
     def block_param_names(self, prefix):
@@ -171,10 +179,15 @@ class UNetEngine:
             cats.append(cat)
             p = f"downs.{i}"
             skip = Act(cat, 0, f)
-            _, rec = self.block_fwd(P, B, p, cur, skip, dt, train, save, x_f32=x_nhwc if i == 0 else None)
+            if self.fused_pool_fwd:
+                _, rec = self.block_fwd(P, B, p, cur, skip, dt, train, save, x_f32=x_nhwc if i == 0 else None, pool=True)
+                cur, code = self._pooled
+                self._pooled = None
+            else:
+                _, rec = self.block_fwd(P, B, p, cur, skip, dt, train, save, x_f32=x_nhwc if i == 0 else None)
+                cur, code = ops.maxpool_fwd(skip)
             if save:
                 sv.blocks[p] = rec
-            cur, code = ops.maxpool_fwd(skip)
             if save:
                 sv.codes.append(code)
             h, w = h // 2, w // 2

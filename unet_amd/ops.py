@@ -393,6 +393,21 @@ def affine_act(z: Act, y: Act, st: BNState, relu=True):
                                 _p(st.scale), _p(st.shift), z.M, z.C, _stream()), "affine_act")
 
 
+def affine_act_pool(z: Act, y: Act, st: BNState, relu=True):
+    """y = relu(z*scale+shift) and its 2x2 max-pool in one pass -> (pooled dense Act, uint8 code)."""
+    z.check(); y.check()
+    if z.C != y.C or z.M != y.M or z.dt != y.dt or st.scale.numel() != z.C:
+        raise UNetHipError("affine_act_pool: shape mismatch")
+    if z.H % 2 or z.W % 2:
+        raise UNetHipError(f"affine_act_pool: H and W must be even, got {z.H}x{z.W}")
+    pooled = dense(z.N, z.H // 2, z.W // 2, z.C, z.dt, z.buf.device)
+    code = torch.empty((z.N, z.H // 2, z.W // 2, z.C), dtype=torch.uint8, device=z.buf.device)
+    check(lib().unet_affine_act_pool(z.dt, 1 if relu else 0, _p(z.buf), z.ld, z.off, _p(y.buf), y.ld, y.off,
+                                     _p(st.scale), _p(st.shift), _p(pooled.buf), _p(code), z.N, z.H, z.W, z.C, _stream()),
+          "affine_act_pool")
+    return pooled, code
+
+
 def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True, want_dbias=True):
     """-> (dgamma, dbeta, dbias|None); dz is written."""
     dy.check(); z.check(); dz.check()

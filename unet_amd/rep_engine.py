@@ -29,6 +29,7 @@ class RepUNetEngine(UNetEngine):
     def __init__(self, features, in_channels, n_classes, kernel_sizes, norm):
         super().__init__(features, in_channels, n_classes)
         self.fused_pool_bwd = False     # the multi-branch blocks take a materialised dy
+        self.fused_pool_fwd = False
         self.ks = sorted(kernel_sizes)
         self.norm = norm
         for k in self.ks:
