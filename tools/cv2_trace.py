@@ -14,13 +14,17 @@ w = torch.randn((cout, cin, 3, 3), device=dev) * (cin * 9) ** -0.5
 wf = ops.pack_weights(w, 0, dt); bias = torch.zeros(cout, device=dev)
 trace = torch.zeros(4096, dtype=torch.int64, device=dev)
 run = (lambda: ops.conv_fwd(x, wf, bias, y, 3, 3, cin, cout, stats=True)) if mode == "fwd" else (lambda: ops.conv_fwd(x, wf, None, y, 3, 3, cin, cout))
-for _ in range(3): run()
+for _ in range(3 if '--hot' not in sys.argv else 4000): run()      # --hot: ~2 s of back-to-back launches first
 torch.cuda.synchronize()
 L = lib(); L.unet_debug_set_trace.argtypes = [ctypes.c_void_p]
 assert L.unet_debug_set_trace(trace.data_ptr()) == 0
 run(); torch.cuda.synchronize()
 L.unet_debug_set_trace(None)
-t = trace.cpu()[:2048].view(2, 1024)[:, :1000].reshape(2, 500, 2)
+tc = trace.cpu()
+ck = [int(v) for v in tc[2048:2052]]
+if ck[3] > ck[1]:
+    print(f"in-kernel clock: {(ck[2] - ck[0]) / (ck[3] - ck[1]) * 100:.0f} MHz over {ck[3] - ck[1]} ticks of the 100 MHz counter")
+t = tc[:2048].view(2, 1024)[:, :1000].reshape(2, 500, 2)
 names = {1: "phase start", 2: "mfma issued", 3: "dma waited", 4: "barrier passed", 5: "refill issued", 6: "epilogue done", 7: "first half mfma", 8: "late refill", 9: "epi: first group packed", 10: "epi: half the groups stored"}
 for wv in range(2):
     ev = [(int(a), int(b)) for a, b in t[wv] if int(b) != 0]

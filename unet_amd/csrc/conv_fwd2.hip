@@ -74,6 +74,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #ifdef CV2_TRACE
     unsigned long long* trc = (g_cv2_trace && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0) ? g_cv2_trace + (wave >> 2) * 1024 : nullptr;
     int tn = 0;
+    // in-kernel clock: shader-cycle counter against the 100 MHz real-time counter, around the whole kernel
+    if (trc && wave == 0) { g_cv2_trace[2048] = __builtin_amdgcn_s_memtime(); g_cv2_trace[2049] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 
     // ---- per-lane fragment bases ------------------------------------------------------------------
@@ -96,16 +98,28 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // out-of-range offset and the hardware writes zeros.  Per tile one bit mask says which of the
     // lane's five halo pieces lie inside the image; channel counts that are not multiples of the tile
     // (never in the U-Net) take the GENERIC path that recomputes everything per piece.
+    // PRODUCER WAVES.  With 128-channel tiles (WC == 2) only waves 0-3 issue DMA, twice the pieces each; their
+    // SIMD partners (waves 4-7) never do.  After a barrier the partner therefore has the matrix pipe to itself
+    // while the producer issues, and the producer has it while the partner waits at the next barrier: the two
+    // waves of a SIMD run in anti-phase by construction instead of stalling on DMA issue side by side.
+    constexpr bool ASYM = WC == 2;
+    constexpr int NPROD = ASYM ? 4 : 8;                       // waves that issue DMA
+    constexpr int HPW = C::H_PIECES / NPROD;                  // halo pieces per producer wave
+    static_assert(C::H_PIECES % NPROD == 0, "halo pieces must divide among the producer waves");
+    const bool producer = !ASYM || wave < 4;
     const int dl = lane >> 2, ds = lane & 3;       // record within the piece, 16-byte slot
     const int wq = ds ^ swz64(dl);                 // weight source chunk (record index % 16 == dl)
     const unsigned woff = (unsigned)(dl * a.Cin + wq * 8) * 2u;
+    // per-lane source offset of halo piece `piece`; kept in registers for the symmetric scheme (5 per lane),
+    // recomputed per request for the producer scheme (10 per lane would not fit the register budget)
+    auto h_off_calc = [&](int piece, int lane_) -> unsigned {
+        const int r = piece * 16 + (lane_ >> 2);
+        const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
+        return r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + ((lane_ & 3) ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
+    };
     unsigned hoff[5];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const int r = (wave + 8 * i) * 16 + dl;
-        const int hr = r / HP, hc = r - hr * HP;
-        hoff[i] = r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + (ds ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
-    }
+    for (int i = 0; i < 5; ++i) hoff[i] = ASYM ? 0u : h_off_calc(wave + 8 * i, lane);
     constexpr bool generic = GEN;
     const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
     const char* wg = (const char*)a.w;
@@ -120,16 +134,16 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         o.h0 = th_i * C::TH; o.w0 = tw_i * C::TW;
         return o;
     };
-    // bit i: halo piece wave+8i of this lane lies inside the image for tile t
+    // bit i: halo piece wave + NPROD*i of this lane lies inside the image for tile t
     auto halo_mask = [&](const Tile& t) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         unsigned m = 0;
-        if (r0 >= 0 && r0 + C::TH + 2 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return 0x1fu;     // interior tile (wave-uniform)
+        if (r0 >= 0 && r0 + C::TH + 2 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return (1u << HPW) - 1u;     // interior tile (wave-uniform)
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int r = (wave + 8 * i) * 16 + (lane_ >> 2);
+        for (int i = 0; i < HPW; ++i) {
+            const int r = (wave + NPROD * i) * 16 + (lane_ >> 2);
             const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
             if ((unsigned)(r0 + hr) < (unsigned)a.Hin && (unsigned)(c0 + hc) < (unsigned)a.Win) m |= 1u << i;
         }
@@ -138,6 +152,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
     auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot) {
         int cnt = 0;
+        if (!producer) return cnt;
         if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) {
             ++cnt;
             // the tile's biases ride with its first weights (wave 0, one piece; lanes past the block read zeros)
@@ -146,8 +161,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                           __builtin_amdgcn_readfirstlane(sb + C::OFF_BIAS + bslot * 1024));
         }
 #pragma unroll
-        for (int i = 0; i < (C::W_PIECES + 7) / 8; ++i) {
-            const int p = wave + 8 * i;
+        for (int i = 0; i < (C::W_PIECES + NPROD - 1) / NPROD; ++i) {
+            const int p = wave + NPROD * i;
             if (p < C::W_PIECES) {
                 const int r0 = p * 16;
                 const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
@@ -170,19 +185,24 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     auto issue_h = [&](const Tile& t, int c, int hstage, unsigned mask) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         const long long offu = (((long long)t.n * a.Hin + r0) * a.Win + c0) * a.ldx * 2 + c * 64;          // wave-uniform
+        if (!producer) return 0;
         const i32x4_t rsrc = make_rsrc(xg + offu, LDS_DMA_RECORDS);
+        int lane_h = lane;
+        if (ASYM) asm volatile("" : "+v"(lane_h));           // keep the offset arithmetic inside the refill
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            unsigned v = ((mask >> i) & 1u) ? hoff[i] : LDS_DMA_OOB;
+        for (int i = 0; i < HPW; ++i) {
+            const int piece = wave + NPROD * i;
+            unsigned v = ((mask >> i) & 1u) ? (ASYM ? h_off_calc(piece, lane_h) : hoff[i % 5]) : LDS_DMA_OOB;
             if (generic) {
                 int lane_ = lane;
                 asm volatile("" : "+v"(lane_));
-                const int r = (wave + 8 * i) * 16 + (lane_ >> 2);
+                const int r = piece * 16 + (lane_ >> 2);
                 const int hr = (r * 241) >> 13, hc = r - hr * HP;
                 if (c * 32 + ((lane_ & 3) ^ swz64(hc)) * 8 >= a.Cin) v = LDS_DMA_OOB;
             }
-            lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + (wave + 8 * i) * 1024));
+            lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + piece * 1024));
         }
+        return HPW;
     };
 
     // ---- issue-side cursors: the next weight phase and the next halo chunk to request ------------------
@@ -218,8 +238,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     };
     auto push_h = [&]() {
         if (!hq_.valid) return;
-        issue_h(hq_.t, hq_.c, hstage_i, hmask);
-        n_issued += 5;
+        n_issued += issue_h(hq_.t, hq_.c, hstage_i, hmask);
         if (hstage_i) h_mark1 = n_issued; else h_mark0 = n_issued;
         hstage_i ^= 1;
         if (++hq_.c == nchunks) { next_tile(hq_); if (hq_.valid) hmask = halo_mask(hq_.t); }
@@ -244,7 +263,10 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         else if (allowed == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if (allowed == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (allowed == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (allowed < 10) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (allowed < 12) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (allowed < 16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     };
     // prologue: phases 0 and 1 and halo chunk 0 (one-phase chunks: halo chunks 0 and 1)
     push_w(); push_h(); push_w();
@@ -255,9 +277,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     int tile_i = lblock, tseq = 0;
     Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
-    // STAGGER: waves 0-3 refill right after the barrier, their SIMD partners (waves 4-7) in the middle of
-    // the next phase's MFMAs, so that on every SIMD one wave issues DMA while the other feeds the matrix pipe.
-    const bool late = wave >= 4;
+    // STAGGER (symmetric scheme, 64-channel tiles): waves 0-3 refill right after the barrier, their SIMD partners
+    // (waves 4-7) in the middle of the next phase's MFMAs.
+    const bool late = !ASYM && wave >= 4;
     int late_ph = -1;          // the refill waves 4-7 still owe (-1: none)
     bool h_owed = false;       // waves 0-3, one-phase chunks: the halo request held back until after the epilogue
     for (;;) {
@@ -313,7 +335,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // ---- the next phase's weights (and, before a new chunk, its halo) must have landed; younger
                 // requests stay in flight across the barrier -----------------------------------------------
                 STAMP(2);
-                {
+                if (producer) {
                     int need = ws ? w_mark0 : w_mark1;
                     if (ph == NPH - 1) need = max(need, hs ? h_mark0 : h_mark1);
                     wait_landed(need);
@@ -492,6 +514,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         if (tile_i >= total_tiles) break;
         cur = decode(tile_i);
     }
+#ifdef CV2_TRACE
+    if (trc && wave == 0) { g_cv2_trace[2050] = __builtin_amdgcn_s_memtime(); g_cv2_trace[2051] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }
 
 template <int WC, bool GEN>
