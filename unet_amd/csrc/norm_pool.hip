@@ -116,11 +116,49 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z
 }
 
 // Block-level reduction of per-thread [NV] partials over the PL pixel lanes, then fp64 atomics.
+// Power-of-two channel-group counts (every U-Net width) first reduce inside the wave with shuffles and need only
+// 4 x min(G,64) x NV floats of LDS (2 KB at C=64): small enough for these HBM-bound kernels to stay resident next to
+// a weight-gradient kernel that holds 151 KB of the CU's LDS (engine.wgrad_async).  reduce_lds_bytes() is the size.
+static inline size_t reduce_lds_bytes(int G, int NV) {
+    const bool pow2 = (G & (G - 1)) == 0;
+    return pow2 ? (size_t)4 * (G < 64 ? G : 64) * NV * sizeof(float) : (size_t)256 * NV * sizeof(float);
+}
+
 template <int NV>
 __device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const float (&part)[NV], int epv, int C,
                                                     double* acc, int acc_stride /* values per channel */) {
-    // layout in LDS: [pl][cg][NV]
     extern __shared__ float red_lds[];
+    const int G = m.G;
+    if ((G & (G - 1)) == 0) {
+        // thread t holds channel group t % G; inside a wave equal groups sit at lane strides G, 2G, ...
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = part[i];
+        for (int st = G; st < 64; st <<= 1) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], st);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, SL = G < 64 ? G : 64;
+        if (lane < SL) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) red_lds[(w * SL + lane) * NV + i] = v[i];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < G * NV; i += 256) {
+            const int cg = i / NV, r = i - cg * NV;
+            float sum = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const int off = (cg - ww * 64) & (G - 1);          // lane of wave ww that held group cg, if any
+                if (off < 64) sum += red_lds[(ww * SL + (off & (SL - 1))) * NV + r];
+            }
+            const int k = r / epv, e = r - k * epv;
+            const int c = cg * epv + e;
+            if (c < C) atomicAdd(&acc[c * acc_stride + k], (double)sum);
+        }
+        return;
+    }
+    // general G: layout in LDS [pl][cg][NV]
     if (m.active) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) red_lds[(m.pl * m.G + m.cg) * NV + i] = part[i];
@@ -534,7 +572,7 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
     const int grid = grid_for(M, PL);
     if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
-    const size_t lds1 = (size_t)256 * 2 * epv * sizeof(float), lds2 = (size_t)256 * epv * sizeof(float);
+    const size_t lds1 = reduce_lds_bytes(C / epv, 2 * epv), lds2 = reduce_lds_bytes(C / epv, epv);
     float* c1 = c1c2_ws; float* c2 = c1c2_ws + C;
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
 #define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
@@ -600,7 +638,7 @@ extern "C" int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, lon
     const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
     const int grid = grid_for(M, PL);
     if (hipMemsetAsync(acc_ws, 0, sizeof(double) * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
-    const size_t lds = (size_t)256 * epv * sizeof(float);
+    const size_t lds = reduce_lds_bytes(C / epv, epv);
     if (dtype == UNET_BF16)
         hipLaunchKernelGGL((channel_sum_kernel<__bf16>), dim3(grid), dim3(256), lds, s, (const __bf16*)x, ldx, xoff, M, C, acc_ws);
     else

@@ -44,6 +44,9 @@ class UNetEngine:
         self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
         self.fused_pool_fwd = True   # UNet: max-pool fused into the BN+ReLU pass of the level's second conv
         self._pooled = None
+        self.overlap_wgrad = True    # weight gradients on a side stream (wgrad_async)
+        self._side_streams = {}
+        self._side_busy = False
 
     # ------------------------------------------------------------------ helpers
     def ws(self, device) -> Workspace:
@@ -51,6 +54,35 @@ class UNetEngine:
         if w is None:
             w = self._ws[device] = Workspace(device)
         return w
+
+    def _side(self, device):
+        st = self._side_streams.get(device)
+        if st is None:
+            st = self._side_streams[device] = (torch.cuda.Stream(device), Workspace(device))
+        return st
+
+    def wgrad_async(self, device, fn, tensors):
+        """Run fn(workspace) -- a weight-gradient kernel sequence -- on the side stream, ordered after everything
+        queued so far on the current stream.  Weight gradients are off the backward critical path
+        (dz -> dgrad -> BN backward -> dz ...), MFMA-bound, and leave registers and LDS for a second resident kernel,
+        so they overlap with the HBM-bound BN / pooling kernels of the next layer.  join_side() orders the current
+        stream after them."""
+        if not self.overlap_wgrad:
+            return fn(self.ws(device))
+        main = torch.cuda.current_stream(device)
+        side, ws_side = self._side(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = fn(ws_side)
+        for t in tensors:
+            t.record_stream(side)            # the caching allocator must not hand these out again before `side` is done
+        self._side_busy = True
+        return out
+
+    def join_side(self, device):
+        if self._side_busy:
+            torch.cuda.current_stream(device).wait_stream(self._side(device)[0])
+            self._side_busy = False
 
     def packed(self, name, p: torch.Tensor, mode, dt):
         key = (name, mode, dt)
@@ -228,7 +260,7 @@ class UNetEngine:
             dg, db_, dbias = ops.bn_relu_bwd(dy, z2, dz2, r2.st, ws)
         grads[r2.bnp + ".weight"], grads[r2.bnp + ".bias"], grads[r2.bname] = dg, db_, dbias
         w2 = P[r2.wname]
-        grads[r2.wname] = ops.conv_wgrad(dz2, r2.xin, 3, 3, ws)[0].view_as(w2)
+        grads[r2.wname] = self.wgrad_async(dev, lambda w_: ops.conv_wgrad(dz2, r2.xin, 3, 3, w_)[0].view_as(w2), [dz2.buf, r2.xin.buf])
         dy1 = ops.dense(z2.N, z2.H, z2.W, w2.shape[1], dt, dev)
         ops.conv_fwd(dz2, self.packed(r2.wname, w2, 1, dt), None, dy1, 3, 3, w2.shape[0], w2.shape[1])
         del dz2
@@ -240,9 +272,9 @@ class UNetEngine:
         del dy1
         w1 = P[r1.wname]
         if r1.first:
-            grads[r1.wname] = ops.conv_first_wgrad(dz1, r1.x_f32, 3, 3, ws)
+            grads[r1.wname] = self.wgrad_async(dev, lambda w_: ops.conv_first_wgrad(dz1, r1.x_f32, 3, 3, w_), [dz1.buf, r1.x_f32])
             return None
-        grads[r1.wname] = ops.conv_wgrad(dz1, r1.xin, 3, 3, ws)[0].view_as(w1)
+        grads[r1.wname] = self.wgrad_async(dev, lambda w_: ops.conv_wgrad(dz1, r1.xin, 3, 3, w_)[0].view_as(w1), [dz1.buf, r1.xin.buf])
         if not need_dx:
             return None
         Cin = w1.shape[1]
@@ -268,6 +300,7 @@ class UNetEngine:
 
         def emit(names):
             if grad_hook is not None:
+                self.join_side(dev)          # the reducer reads these gradients in current-stream order
                 grad_hook(names, [grads[n] for n in names])
 
         dlogits = dlogits.contiguous().float()
@@ -292,7 +325,7 @@ class UNetEngine:
                 grads[tname + ".bias"] = sums.view(-1, 2)[:, 0].contiguous()
             else:
                 grads[tname + ".bias"] = ops.channel_sum(dup, ws)
-            grads[tname + ".weight"] = ops.convT_wgrad(xin, dup, ws)
+            grads[tname + ".weight"] = self.wgrad_async(dev, lambda w_: ops.convT_wgrad(xin, dup, w_), [xin.buf, dup.buf])
             dcur = ops.dense(xin.N, xin.H, xin.W, xin.C, dt, dev)
             ops.convT_dgrad(dup, self.packed(tname + ".weight", P[tname + ".weight"], 3, dt), xin.C, dcur)
             del dup
@@ -307,4 +340,5 @@ class UNetEngine:
             dskips[i] = None
             dcur = self.block_bwd(P, sv, f"downs.{i}", dy2, grads, dt, need_dx=(i > 0))
             emit(self.block_param_names(f"downs.{i}"))
+        self.join_side(dev)
         return grads
