@@ -178,11 +178,12 @@ __global__ __launch_bounds__(256) void conv_first1_fwd_kernel(const float* __res
         const int h0 = th * FIRST_R, wq = tw * PL + pl;
         if (!active || wq >= W) continue;
         const int h1 = min(h0 + FIRST_R, H);
-        float ra[3], rb[3], rc[3];
+        float ra[3], rb[3], rc[3], rn[3];                 // rows h-1, h, h+1 and the prefetched row h+2
         first_row3(xi, h0 - 1, wq, H, W, ra);
         first_row3(xi, h0, wq, H, W, rb);
+        first_row3(xi, h0 + 1, wq, H, W, rc);
         for (int h = h0; h < h1; ++h) {
-            first_row3(xi, h + 1, wq, H, W, rc);
+            first_row3(xi, h + 2, wq, H, W, rn);          // in flight under this row's 72 FMAs
             float acc[EPV];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(256) void conv_first1_fwd_kernel(const float* __res
             }
             *(uint4*)(zi + ((long long)h * W + wq) * Cout + cg * EPV) = Vec16<T>::pack(acc);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; rc[k] = rn[k]; }
         }
     }
     if (stats != nullptr) {
@@ -242,13 +243,16 @@ __global__ __launch_bounds__(256) void conv_first1_wgrad_kernel(const T* __restr
         const int h1 = min(h0 + FIRST_R, H);
         const float* xi = x + (long long)n * H * W;
         const T* di = dz + (long long)n * H * W * Cout;
-        float ra[3], rb[3], rc[3];
+        float ra[3], rb[3], rc[3], rn[3];
         first_row3(xi, h0 - 1, wq, H, W, ra);
         first_row3(xi, h0, wq, H, W, rb);
+        first_row3(xi, h0 + 1, wq, H, W, rc);
+        uint4 gq = *(const uint4*)(di + ((long long)h0 * W + wq) * Cout + cg * EPV);
         for (int h = h0; h < h1; ++h) {
-            first_row3(xi, h + 1, wq, H, W, rc);
+            first_row3(xi, h + 2, wq, H, W, rn);          // next row's inputs and gradient in flight under the FMAs
+            const uint4 gn = h + 1 < h1 ? *(const uint4*)(di + ((long long)(h + 1) * W + wq) * Cout + cg * EPV) : gq;
             float g[EPV];
-            Vec16<T>::unpack(*(const uint4*)(di + ((long long)h * W + wq) * Cout + cg * EPV), g);
+            Vec16<T>::unpack(gq, g);
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -257,8 +261,9 @@ __global__ __launch_bounds__(256) void conv_first1_wgrad_kernel(const T* __restr
                     part[3 + k][e] = fmaf(g[e], rb[k], part[3 + k][e]);
                     part[6 + k][e] = fmaf(g[e], rc[k], part[6 + k][e]);
                 }
+            gq = gn;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; rc[k] = rn[k]; }
         }
     }
     // reduce over pixel lanes one tap at a time through LDS [pl][cg][EPV] (as the generic kernel)

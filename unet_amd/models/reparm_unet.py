@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..rep_engine import RepUNetEngine
-from .unet import _UNetFn, resolve_dtype
+from .unet import SlotCache, _UNetFn, resolve_dtype
 
 
 def getConv2D(in_channels, out_channels, kernel_size=(3, 3), stride=1, padding=0, groups=1, bias=True):
@@ -120,7 +120,7 @@ class ReparamDoubleConv(nn.Module):
         raise ops.UNetHipError("ReparamDoubleConv is executed by ReparamUNet.forward on the HIP engine")
 
 
-class ReparamUNet(nn.Module):
+class ReparamUNet(SlotCache, nn.Module):
     def __init__(self, in_channels=1, n_classes=3, features=[64, 128, 256, 512], kernel_sizes=[3], norm="group"):
         super().__init__()
         if norm not in ("group", "batch"):
@@ -149,12 +149,10 @@ class ReparamUNet(nn.Module):
         self.compute_dtype = None
         self._grad_hook = None
 
-    @property
-    def _param_names(self):
-        return [n for n, _ in self.named_parameters()]
-
     def forward(self, x, current_epoch=None):
-        params = [p for _, p in self.named_parameters()]
+        named = self.named_params_fast()
+        params = [p for _, p in named]
+        self._cur_names = [n for n, _ in named]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
 
@@ -163,7 +161,7 @@ class ReparamUNet(nn.Module):
         so the work is queued behind it instead of sitting in front of the next forward)."""
         dt = getattr(self._engine, "_last_dt", None)
         if dt is not None:
-            self._engine.prepack(dict(self.named_parameters()), dt)
+            self._engine.prepack(dict(self.named_params_fast()), dt)
 
     def make_deploy_skeleton(self):
         """Turn an un-deployed model into the deploy-mode STRUCTURE (one zero-initialised `mergedConv` per
@@ -179,6 +177,7 @@ class ReparamUNet(nn.Module):
                 module.mergedFlag = True
                 delattr(module, "conv_list")
         self._engine._packed.clear()
+        self.invalidate_slots()
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         deployed_keys = any(".mergedConv." in k for k in state_dict)
@@ -194,6 +193,7 @@ class ReparamUNet(nn.Module):
             if isinstance(module, MultiConvBlock):
                 module.mergeMulKernels()
         self._engine._packed.clear()
+        self.invalidate_slots()
         print("[ReparamUNet] Fusion complete.")
 
 

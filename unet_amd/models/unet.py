@@ -46,12 +46,41 @@ def resolve_dtype(module) -> int:
     return ops.BF16 if torch.is_autocast_enabled() else ops.F32
 
 
+class SlotCache:
+    """named_parameters() / named_buffers() without walking the module tree every forward: the (owning dict, key,
+    qualified name) slots are collected once, the tensors are fetched from the dicts at each call, so replaced
+    tensors (.to(), load_state_dict(assign=True)) are seen; only a change of STRUCTURE needs invalidate_slots()
+    (switch_to_deploy / make_deploy_skeleton call it)."""
+
+    def _slots(self):
+        c = self.__dict__.get("_slot_cache")
+        if c is None:
+            ps, bs = [], []
+            for mname, mod in self.named_modules():
+                pre = mname + "." if mname else ""
+                for k in mod._parameters:
+                    ps.append((mod._parameters, k, pre + k))
+                for k in mod._buffers:
+                    bs.append((mod._buffers, k, pre + k))
+            c = self.__dict__["_slot_cache"] = (ps, bs)
+        return c
+
+    def invalidate_slots(self):
+        self.__dict__.pop("_slot_cache", None)
+
+    def named_params_fast(self):
+        return [(n, d[k]) for d, k, n in self._slots()[0] if d.get(k) is not None]
+
+    def named_buffers_fast(self):
+        return {n: d[k] for d, k, n in self._slots()[1] if d.get(k) is not None}
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, dt, need_grad, x, *params):
-        names = module._param_names
+        names = module._cur_names
         P = dict(zip(names, params))
-        B = dict(module.named_buffers())
+        B = module.named_buffers_fast()
         logits, sv = module._engine.forward(x, P, B, dt, module.training, need_grad)
         ctx.module, ctx.sv, ctx.names = module, sv, names
         ctx.P = P if need_grad else None
@@ -72,7 +101,7 @@ class _UNetFn(torch.autograd.Function):
         return (None, None, None, None, *out)
 
 
-class UNet(nn.Module):
+class UNet(SlotCache, nn.Module):
     def __init__(self, in_channels=1, n_classes=3, features=[64, 128, 256, 512]):
         super().__init__()
         features = list(features)
@@ -97,12 +126,13 @@ class UNet(nn.Module):
         if not 1 <= n_classes <= 8:
             raise ValueError("unet_amd serves 1..8 classes")
         self._engine = UNetEngine(features, in_channels, n_classes)
-        self._param_names = [n for n, _ in self.named_parameters()]
         self.compute_dtype = None
         self._grad_hook = None
 
     def forward(self, x, current_epoch=None):
-        params = [p for _, p in self.named_parameters()]
+        named = self.named_params_fast()
+        params = [p for _, p in named]
+        self._cur_names = [n for n, _ in named]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _UNetFn.apply(self, resolve_dtype(self), need_grad, x, *params)
 
@@ -111,7 +141,7 @@ class UNet(nn.Module):
         so the work is queued behind it instead of sitting in front of the next forward)."""
         dt = getattr(self._engine, "_last_dt", None)
         if dt is not None:
-            self._engine.prepack(dict(self.named_parameters()), dt)
+            self._engine.prepack(dict(self.named_params_fast()), dt)
 
 
 def build_unet(**kwargs):
