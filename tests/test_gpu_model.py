@@ -243,3 +243,37 @@ def test_eval_bn_fold_matches_unfolded(dev, dtype):
     m.load_state_dict(sd)
     a3, b3 = both()
     assert rell2(a3, b3) < tol and rell2(a3, a2) > 1e-2
+
+
+def test_wgrad_side_stream_gives_identical_gradients(dev):
+    """UNET_AMD_OVERLAP_WGRAD mode: weight gradients on a side stream; same numbers, several steps in a row
+    (the caching allocator must not recycle a dz buffer the side stream still reads)."""
+    m, g = build("unet_f8x16x32x64", dev)
+    m.compute_dtype = "bf16"
+    m.train()
+    x, y = g["x"].to(dev), g["y"].to(dev)
+    from unet_amd.losses import get_loss
+    loss_fn = get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)
+
+    def grads(overlap):
+        m._engine.overlap_wgrad = overlap
+        out = None
+        for _ in range(3):
+            m.zero_grad(set_to_none=True)
+            loss_fn(m(x), y).backward()
+            torch.cuda.synchronize()
+            cur = {k: p.grad.clone() for k, p in m.named_parameters()}
+            if out is not None:
+                for k in cur:
+                    if k.endswith(".weight") and cur[k].dim() == 4:
+                        assert torch.equal(cur[k], out[k]), k          # run-to-run reproducible (fixed split order)
+            out = cur
+        return out
+
+    a, b = grads(False), grads(True)
+    m._engine.overlap_wgrad = False
+    for k in a:
+        if k.endswith(".weight") and a[k].dim() == 4:
+            assert torch.equal(a[k], b[k]), k
+        else:
+            torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6)

@@ -21,8 +21,8 @@ x = torch.rand(32, 1, 512, 512, generator=g).to(dev)
 y = (torch.rand(32, 512, 512, generator=g) > 0.95).long().to(dev)
 if nogc:
     gc.disable()
-if "--no-overlap" in sys.argv:         # A/B: weight gradients on the main stream
-    model._engine.overlap_wgrad = False
+if "--overlap" in sys.argv:            # A/B: weight gradients on the side stream
+    model._engine.overlap_wgrad = True
 if "--late-pack" in sys.argv:          # A/B: weights re-packed at the start of the next forward instead
     model.prepack_weights = None
 ts = []

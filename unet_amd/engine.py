@@ -12,6 +12,8 @@ invisible to the caller:
 """
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -44,7 +46,12 @@ class UNetEngine:
         self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
         self.fused_pool_fwd = True   # UNet: max-pool fused into the BN+ReLU pass of the level's second conv
         self._pooled = None
-        self.overlap_wgrad = True    # weight gradients on a side stream (wgrad_async)
+        # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
+        # filling between the big persistent kernels (a wgrad block starts on a CU the moment the dgrad conv's block
+        # there retires; the two cannot share a CU, 134 + 151 KB of LDS).  OFF by default because queued-behind time
+        # then counts into every kernel's measured duration and the per-kernel roofline numbers stop meaning anything;
+        # UNET_AMD_OVERLAP_WGRAD=1 (or engine.overlap_wgrad = True) turns it on.
+        self.overlap_wgrad = os.environ.get("UNET_AMD_OVERLAP_WGRAD", "0") == "1"
         self._side_streams = {}
         self._side_busy = False
 
