@@ -99,10 +99,11 @@ class DataParallel(nn.Module):
         for ts in by_dtype.values():
             flat = torch.cat([t.reshape(-1) for t in ts])
             dist.broadcast(flat, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
-            off = 0
+            off, views = 0, []
             for t in ts:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
+                views.append(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
+            torch._foreach_copy_(ts, views)          # one multi-tensor kernel, not one copy per buffer
 
     def forward(self, *args, **kwargs):
         if self.world > 1 and self.broadcast_buffers and self.module.training:
@@ -114,5 +115,9 @@ class DataParallel(nn.Module):
         avg = self.reducer.finish()
         for n, g in avg.items():
             p = self._params[n]
-            if p.grad is not None:
-                p.grad.copy_(g)
+            if p.grad is None:
+                continue
+            if g.dtype == p.grad.dtype:
+                p.grad = g                  # a contiguous view of the reduced bucket (DDP's gradient_as_bucket_view)
+            else:
+                p.grad.copy_(g)             # communication dtype differs from the gradient's
