@@ -159,24 +159,40 @@ __global__ __launch_bounds__(512) void convT2_kernel(CT2Args a, FastDiv d_n, Fas
                 const int osy = DGRAD ? 1 : 2, Wd = osy * a.W;
                 const size_t pix0 = ((size_t)(cur.n * osy * a.H + osy * (cur.h0 + wr * 4) + qi)) * Wd + osy * cur.w0 + qj;
                 char* ybase = (char*)a.dst + (pix0 * a.ldd + a.doff + chan) * 2;
-                const int rpx = lane >> 3, rch = lane & 7;
+                // lane-derived addresses from an opaque copy of the lane id (hipcc would otherwise hoist them out of the
+                // tile loop and hold ~10 registers across the main loop), bias added into the accumulators once,
+                // one v_cvt_pk_bf16_f32 per pair: the same epilogue as conv3x3_v2_kernel
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int ge = lane_e >> 4, l15e = lane_e & 15;
+                const int rpx = lane_e >> 3, rch = lane_e & 7;
                 const unsigned st_off = (unsigned)(osy * rpx * a.ldd + rch * 8) * 2u;
                 const size_t row_stride = (size_t)osy * Wd * a.ldd * 2, half_stride = (size_t)osy * 8 * a.ldd * 2;
+                if (!DGRAD) {
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        const float4 b4 = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * ge) * 4);
+#pragma unroll
+                        for (int pg = 0; pg < 8; ++pg) {
+                            acc[ct][pg][0] += b4.x; acc[ct][pg][1] += b4.y; acc[ct][pg][2] += b4.z; acc[ct][pg][3] += b4.w;
+                        }
+                    }
+                }
+                char* wbase = scr + (l15e >> 3) * 8192 + (l15e & 7) * 128 + (ge & 1) * 8;
+                const char* rbase = scr + rpx * 128 + ((rch ^ rpx) << 4);
 #pragma unroll
                 for (int pg = 0; pg < 8; ++pg) {
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
-                        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (!DGRAD) bv = *(const float4*)(smem + C::OFF_BIAS + tseq * 1024 + (wc * 64 + ct * 16 + 4 * g) * 4);
                         uint2 pk;
-                        pk.x = Vec16<__bf16>::pk(acc[ct][pg][0] + bv.x, acc[ct][pg][1] + bv.y);
-                        pk.y = Vec16<__bf16>::pk(acc[ct][pg][2] + bv.z, acc[ct][pg][3] + bv.w);
-                        *(uint2*)(scr + (l15 >> 3) * 8192 + (l15 & 7) * 128 + (((ct * 2 + (g >> 1)) ^ (l15 & 7)) << 4) + (g & 1) * 8) = pk;
+                        pk.x = cvt_pk_bf16(acc[ct][pg][0], acc[ct][pg][1]);
+                        pk.y = cvt_pk_bf16(acc[ct][pg][2], acc[ct][pg][3]);
+                        *(uint2*)(wbase + (((ct * 2 + (ge >> 1)) ^ (l15e & 7)) << 4)) = pk;
                     }
                     char* pp = ybase + (pg >> 1) * row_stride + (pg & 1) * 2 * half_stride + st_off;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const uint4 val = *(const uint4*)(scr + h * 8192 + rpx * 128 + ((rch ^ rpx) << 4));
+                        const uint4 val = *(const uint4*)(rbase + h * 8192);
                         *(uint4*)(pp + h * half_stride) = val;
                     }
                 }
