@@ -1,0 +1,223 @@
+"""BASELINE.json configs[1] sizes (32x1x512x512, widths 64..1024, bf16): the oracle cannot run these in seconds, so the
+kernels are checked through size-independent properties that have exact answers.
+
+  * 3x3 conv with a one-hot kernel is a zero-padded SHIFT of its input: bit-exact at every tile border, for forward and
+    (flipped weights) dgrad, at each U-Net level's real shape, including the split-destination dgrad of a decoder level;
+  * weight gradient with all-ones operands counts valid positions: N*(H-|dh|)*(W-|dw|), an integer fp32 holds exactly;
+  * max-pool -> un-pool keeps the gradient sum and puts it on arg-max positions only; the fused BN-apply+pool equals
+    the two kernels bit for bit at full size;
+  * BN: after apply (no ReLU) every channel has mean 0 / variance 1 within bf16 rounding; backward's dz sums to 0;
+  * ConvTranspose2d(2,2) with a one-hot kernel is a pixel scatter;
+  * Dice+CE of uniform logits is ln 2 + the closed-form Dice term; argmax of one-hot logits returns the labels;
+  * eval-mode forward is batch-independent bit for bit; one full training step is finite and two identical steps
+    from the same state give identical parameters (run-to-run reproducibility of conv / wgrad / optimizer).
+"""
+import math
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 32
+LEVELS = [(64, 512), (128, 256), (256, 128), (512, 64), (1024, 32)]        # (channels, H=W) of the U-Net's convs
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def ops_mod():
+    from unet_amd import ops
+    return ops
+
+
+def rand_act(ops, n, h, w, c, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return ops.Act((torch.randn((n, h, w, c), generator=g, device=dev) * 0.5).bfloat16(), 0, c)
+
+
+def shift_ref(x, dh, dw):
+    """y[n,h,w,c] = x[n,h+dh,w+dw,c] with zero padding (NHWC)."""
+    n, H, W, c = x.shape
+    y = torch.zeros_like(x)
+    hs, he = max(0, -dh), min(H, H - dh)
+    ws_, we = max(0, -dw), min(W, W - dw)
+    y[:, hs:he, ws_:we] = x[:, hs + dh:he + dh, ws_ + dw:we + dw]
+    return y
+
+
+@pytest.mark.parametrize("level", LEVELS)
+@pytest.mark.parametrize("tap", [(0, 0), (1, 1), (2, 1), (0, 2)])
+def test_one_hot_conv_is_a_shift(dev, level, tap):
+    ops = ops_mod()
+    C, H = level
+    x = rand_act(ops, N, H, H, C, dev, 1)
+    w = torch.zeros((C, C, 3, 3), device=dev)
+    idx = torch.arange(C, device=dev)
+    perm = (idx * 7 + 3) % C if C % 7 else (idx + 5) % C              # output channel o reads input channel perm[o]
+    w[idx, perm, tap[0], tap[1]] = 1.0
+    y = ops.dense(N, H, H, C, ops.BF16, dev)
+    ops.conv_fwd(x, ops.pack_weights(w, 0, ops.BF16), None, y, 3, 3, C, C)
+    ref = shift_ref(x.buf, tap[0] - 1, tap[1] - 1)[..., perm]
+    assert torch.equal(y.buf, ref)
+    # dgrad = correlation with the flipped, transposed kernel: input channel i receives output channel inv[i], shifted back
+    dx = ops.dense(N, H, H, C, ops.BF16, dev)
+    ops.conv_fwd(x, ops.pack_weights(w, 1, ops.BF16), None, dx, 3, 3, C, C)
+    inv = torch.empty_like(perm); inv[perm] = idx
+    assert torch.equal(dx.buf, shift_ref(x.buf, 1 - tap[0], 1 - tap[1])[..., inv])
+
+
+def test_split_destination_dgrad_full_size(dev):
+    """First decoder conv of the top level: dgrad of 64 <- 128 channels written to two dense halves, with the per-tile
+    channel sums the ConvTranspose bias gradient is taken from."""
+    ops = ops_mod()
+    Cout, Cin, H = 64, 128, 512
+    dz = rand_act(ops, N, H, H, Cout, dev, 2)
+    w = torch.zeros((Cout, Cin, 3, 3), device=dev)
+    o = torch.arange(Cout, device=dev)
+    w[o, o, 1, 1] = 1.0                     # input channel i < 64 <- output channel i
+    w[o, o + 64, 1, 1] = 2.0                # input channel 64 + i <- 2 * output channel i
+    dskip = ops.dense(N, H, H, 64, ops.BF16, dev)
+    dup = ops.dense(N, H, H, 64, ops.BF16, dev)
+    rows = ops.conv_fwd(dz, ops.pack_weights(w, 1, ops.BF16), None, dskip, 3, 3, Cout, Cin, y2=dup, csplit=64, stats=True)
+    assert torch.equal(dskip.buf, dz.buf)
+    assert torch.equal(dup.buf.float(), 2.0 * dz.buf.float())
+    sums = rows.double().sum(0)[:, 0]
+    ref = dz.buf.double().sum((0, 1, 2))
+    torch.testing.assert_close(sums[:64], ref, rtol=1e-5, atol=1e-2)
+    torch.testing.assert_close(sums[64:], 2 * ref, rtol=1e-5, atol=1e-2)
+
+
+@pytest.mark.parametrize("level", [(64, 512), (128, 256), (512, 64)])
+def test_weight_gradient_of_ones_counts_positions(dev, level):
+    ops = ops_mod()
+    C, H = level
+    ones = ops.Act(torch.ones((N, H, H, C), dtype=torch.bfloat16, device=dev), 0, C)
+    dw = ops.conv_wgrad(ones, ones, 3, 3, ops.Workspace(dev))[0].view(C, C, 3, 3)
+    for kh in range(3):
+        for kw in range(3):
+            exp = float(N * (H - abs(kh - 1)) * (H - abs(kw - 1)))
+            assert float(dw[:, :, kh, kw].min()) == exp and float(dw[:, :, kh, kw].max()) == exp, (kh, kw)
+
+
+@pytest.mark.parametrize("level", [(64, 512), (512, 64)])
+def test_pool_unpool_and_fused_pool_full_size(dev, level):
+    ops = ops_mod()
+    C, H = level
+    z = rand_act(ops, N, H, H, C, dev, 3)
+    g = torch.Generator(device=dev).manual_seed(4)
+    st = ops.BNState(torch.rand(C, generator=g, device=dev) + 0.5, torch.randn(C, generator=g, device=dev) * 0.1)
+    y1, y2 = ops.dense(N, H, H, C, ops.BF16, dev), ops.dense(N, H, H, C, ops.BF16, dev)
+    ops.affine_act(z, y1, st)
+    p1, c1 = ops.maxpool_fwd(y1)
+    p2, c2 = ops.affine_act_pool(z, y2, st)
+    assert torch.equal(y1.buf, y2.buf) and torch.equal(p1.buf, p2.buf) and torch.equal(c1, c2)
+    assert torch.equal(p1.buf, torch.nn.functional.max_pool2d(y1.buf.permute(0, 3, 1, 2).float(), 2).permute(0, 2, 3, 1).bfloat16())
+    dp = rand_act(ops, N, H // 2, H // 2, C, dev, 5)
+    dx = ops.maxpool_bwd(dp, c1, None)
+    nz = dx.buf != 0
+    assert int(nz.sum()) <= dp.buf.numel()                      # at most one position per window
+    torch.testing.assert_close(dx.buf.double().sum((0, 1, 2)), dp.buf.double().sum((0, 1, 2)), rtol=0, atol=1e-6)
+    # gradient lands where the window's maximum is
+    up = torch.repeat_interleave(torch.repeat_interleave(p1.buf, 2, 1), 2, 2)
+    assert bool((y1.buf[nz] == up[nz]).all())
+
+
+@pytest.mark.parametrize("level", [(64, 512), (256, 128)])
+def test_batchnorm_normalises_and_backward_sums_to_zero(dev, level):
+    ops = ops_mod()
+    C, H = level
+    z = rand_act(ops, N, H, H, C, dev, 6)
+    zz = z.buf.double()
+    rows = torch.stack([zz.sum((1, 2)), (zz * zz).sum((1, 2))], -1).float().contiguous()          # one row per image
+    ws = ops.Workspace(dev)
+    gamma = torch.ones(C, device=dev); beta = torch.zeros(C, device=dev)
+    st = ops.bn_finalize(rows, N * H * H, gamma, beta, None, None, None, 0.1, 1e-5, ws)
+    y = ops.dense(N, H, H, C, ops.BF16, dev)
+    ops.affine_act(z, y, st, relu=False)
+    yy = y.buf.double()
+    assert float(yy.mean((0, 1, 2)).abs().max()) < 2e-3
+    assert float((yy.var((0, 1, 2), unbiased=False) - 1).abs().max()) < 1e-2
+    dy = rand_act(ops, N, H, H, C, dev, 7)
+    dz = ops.dense(N, H, H, C, ops.BF16, dev)
+    dg, db, dbias = ops.bn_relu_bwd(dy, z, dz, st, ws, relu=False)
+    scale = float(dy.buf.float().abs().sum((0, 1, 2)).max())
+    assert float(dz.buf.double().sum((0, 1, 2)).abs().max()) < 5e-3 * scale          # sum_p dz = 0 up to bf16 rounding of dz
+    torch.testing.assert_close(db.double(), dy.buf.double().sum((0, 1, 2)), rtol=1e-5, atol=1e-2)
+
+
+def test_conv_transpose_one_hot_is_a_pixel_scatter(dev):
+    ops = ops_mod()
+    Ci, Co, h = 128, 64, 256
+    x = rand_act(ops, N, h, h, Ci, dev, 8)
+    w = torch.zeros((Ci, Co, 2, 2), device=dev)
+    o = torch.arange(Co, device=dev)
+    for q, (i, j) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        w[o + 16 * q, o, i, j] = 1.0                 # output (2h+i, 2w+j, c) = x(h, w, c + 16q)
+    cat = torch.zeros((N, 2 * h, 2 * h, 2 * Co), dtype=torch.bfloat16, device=dev)
+    ops.conv_fwd(x, ops.pack_weights(w, 2, ops.BF16), torch.zeros(Co, device=dev), ops.Act(cat, Co, Co), 1, 1, Ci, 4 * Co, epi=1)
+    assert float(cat[..., :Co].abs().max()) == 0.0          # the skip half is not touched
+    for q, (i, j) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        assert torch.equal(cat[:, i::2, j::2, Co:], x.buf[..., 16 * q:16 * q + Co])
+
+
+def test_loss_and_argmax_closed_forms(dev):
+    ops = ops_mod()
+    H = 512
+    g = torch.Generator(device=dev).manual_seed(9)
+    y = (torch.rand((N, H, H), generator=g, device=dev) > 0.9).long()
+    logits = torch.zeros((N, 2, H, H), device=dev)
+    from unet_amd.losses import get_loss
+    loss = get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)(logits, y)
+    # uniform probabilities 1/2 (losses/segmentation.py:5-14): CE = ln 2; per sample b and class c the Dice term is
+    # (2*0.5*n_bc + eps) / (0.5*M + n_bc + eps) with n_bc the class count and M = H*W; the loss is 1 - their mean.
+    M = float(H * H)
+    n1 = y.sum((1, 2)).double()
+    n = torch.stack([M - n1, n1], 1)
+    dice = 1.0 - ((n + 1e-6) / (0.5 * M + n + 1e-6)).mean()
+    want = math.log(2.0) + float(dice)
+    assert abs(float(loss) - want) < 2e-5, (float(loss), want)
+    ce_only = get_loss("ce", ignore_index=255)(logits, y)
+    assert abs(float(ce_only) - math.log(2.0)) < 1e-6
+    onehot = torch.nn.functional.one_hot(y, 2).permute(0, 3, 1, 2).float().contiguous() * 5.0
+    assert torch.equal(ops.argmax(onehot), y)
+
+
+def test_full_model_eval_is_batch_independent_and_step_reproducible(dev):
+    import copy, logging, types
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    from unet_amd.utils.builders import get_optim
+    from unet_amd.utils.train_step import step_batch
+    torch.manual_seed(0)
+    m = REGISTRY["unet"](in_channels=1, n_classes=2, features=[64, 128, 256, 512]).to(dev)
+    m.compute_dtype = "bf16"
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(N, 1, 512, 512, generator=g).to(dev)
+    y = (torch.rand(N, 512, 512, generator=g) > 0.95).long().to(dev)
+    m.eval()
+    with torch.no_grad():
+        full = m(x)
+        a, b = m(x[:16]), m(x[16:])
+    assert torch.equal(full, torch.cat([a, b]))
+    assert bool(torch.isfinite(full).all())
+    state = copy.deepcopy(m.state_dict())
+
+    def one_step():
+        m.load_state_dict(state)
+        m.train()
+        opt = get_optim("adamw", m.parameters(), lr=1e-4, weight_decay=1e-4)
+        tr = types.SimpleNamespace(optimizer=opt, amp=True, model=m, grad_clip=1.0, cbs=[], current_epoch=1,
+                                   logger=logging.getLogger("t"), loss_fn=get_loss("ce_dice", ignore_index=255))
+        loss, _, info = step_batch(tr, x, y, torch.amp.GradScaler(enabled=False), 1)
+        return info["main_loss"], {k: v.clone() for k, v in m.state_dict().items()}
+
+    l1, s1 = one_step()
+    l2, s2 = one_step()
+    assert math.isfinite(l1) and 0.3 < l1 < 3.0
+    # conv / wgrad / pooling / optimizer are order-deterministic; BN sums use fp64 atomics whose order varies, which can
+    # move a statistic by an ulp: parameters agree to fp32 rounding, conv weights (no atomics on their path) mostly exactly
+    for k in s1:
+        torch.testing.assert_close(s1[k].float(), s2[k].float(), rtol=1e-4, atol=1e-6)
