@@ -101,6 +101,10 @@ def test_pack_weights_multi_bit_exact(dev):
               (torch.randn(64, 40, 3, 3, generator=g).to(dev), 1), (torch.randn(16, 8, 2, 2, generator=g).to(dev), 2),
               (torch.randn(16, 8, 2, 2, generator=g).to(dev), 3), (torch.randn(8, 8, 1, 3, generator=g).to(dev), 0)]
         ws += [(torch.randn(8, 8, 3, 3, generator=g).to(dev), i & 1) for i in range(44)]
+        # forward + dgrad image of ONE source (merged into one tile pass), ragged tiles, Cin=1, 5x5 / 1x5 / 7x7 taps
+        for shape in [(72, 40, 3, 3), (64, 1, 3, 3), (33, 65, 3, 3), (24, 16, 5, 5), (16, 24, 1, 5), (8, 16, 7, 7), (128, 256, 3, 3)]:
+            w = torch.randn(*shape, generator=g).to(dev)
+            ws += [(w, 0), (w, 1)]
         outs = [torch.empty(w.numel(), dtype=ops.torch_dtype(dt), device=dev) for w, _ in ws]
         ops.pack_weights_multi([(w, mode, o) for (w, mode), o in zip(ws, outs)], dt)
         for (w, mode), o in zip(ws, outs):

@@ -163,6 +163,60 @@ __global__ __launch_bounds__(256) void mt_pack_kernel(MTPackTable tb) {
     }
 }
 
+// Conv weights (modes 0 and 1 share one fp32 source): a workgroup stages a 32(o) x TI(i) x NT tile through LDS, reading
+// each source row segment contiguously ONCE, and writes the forward image [tap][O][I] and/or the dgrad image
+// [NT-1-tap][I][O] from it in 64-byte runs.  The per-element gather above touches one cache line per element for the
+// dgrad image (stride I*NT floats between neighbouring lanes).
+constexpr int PT_O = 32, PT_ROW = 288;            // TI*NT <= PT_ROW: TI = 32 for NT <= 9, 8 for NT <= 36
+struct MTPackTileTable {
+    int n;
+    int blk_end[MT_MAX];
+    const float* src[MT_MAX];
+    void* dst0[MT_MAX];             // forward image or null
+    void* dst1[MT_MAX];             // dgrad image or null
+    int O[MT_MAX], I[MT_MAX], NT[MT_MAX];
+};
+static inline int pack_ti(int NT) { return NT <= 9 ? 32 : 8; }
+static inline int pack_tiles(int O, int I, int NT) { return ((O + PT_O - 1) / PT_O) * ((I + pack_ti(NT) - 1) / pack_ti(NT)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void mt_pack_tile_kernel(MTPackTileTable tb) {
+    __shared__ float tile[PT_O][PT_ROW + 1];
+    const int b = blockIdx.x;
+    const int t = mt_find(tb.blk_end, tb.n, b);
+    const int tl = b - (t ? tb.blk_end[t - 1] : 0);
+    const float* __restrict__ src = tb.src[t];
+    T* __restrict__ d0 = (T*)tb.dst0[t];
+    T* __restrict__ d1 = (T*)tb.dst1[t];
+    const int O = tb.O[t], I = tb.I[t], NT = tb.NT[t];
+    const int TI = NT <= 9 ? 32 : 8;
+    const int tiles_i = (I + TI - 1) / TI;
+    const int o0 = (tl / tiles_i) * PT_O, i0 = (tl % tiles_i) * TI;
+    const int no = O - o0 < PT_O ? O - o0 : PT_O, ni = I - i0 < TI ? I - i0 : TI;
+    const int span = ni * NT;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < no; r += 4) {
+        const float* row = src + ((size_t)(o0 + r) * I + i0) * NT;
+        for (int e = lane; e < span; e += 64) tile[r][e] = row[e];
+    }
+    __syncthreads();
+    const int per_tap = PT_O * TI;
+    if (d0) {
+        for (int idx = threadIdx.x; idx < per_tap * NT; idx += 256) {
+            const int tap = idx / per_tap, rem = idx - tap * per_tap;
+            const int r = rem / TI, i = rem - r * TI;
+            if (r < no && i < ni) d0[((size_t)tap * O + o0 + r) * I + i0 + i] = from_f32<T>(tile[r][i * NT + tap]);
+        }
+    }
+    if (d1) {
+        for (int idx = threadIdx.x; idx < per_tap * NT; idx += 256) {
+            const int tap = idx / per_tap, rem = idx - tap * per_tap;
+            const int i = rem / PT_O, r = rem - i * PT_O;
+            if (r < no && i < ni) d1[((size_t)(NT - 1 - tap) * I + i0 + i) * O + o0 + r] = from_f32<T>(tile[r][i * NT + tap]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 
 extern "C" int unet_mt_blocks(int nt, const long long* numel) {
@@ -237,12 +291,46 @@ extern "C" int unet_pack_weights_multi(int dtype, int nt, const int* modes, cons
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
     UNET_CHECK(nt >= 0 && (nt == 0 || (modes && src && dst && O && I && ntaps)), "pack_weights_multi: null argument");
     hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < nt; ++i) {
+        UNET_CHECK(modes[i] >= 0 && modes[i] <= 3, "bad pack mode %d", modes[i]);
+        if (modes[i] >= 2) UNET_CHECK(ntaps[i] == 4, "convT pack needs 4 taps");
+        UNET_CHECK(src[i] && dst[i] && O[i] > 0 && I[i] > 0 && ntaps[i] > 0, "pack_weights_multi: bad tensor %d", i);
+        UNET_CHECK((long long)O[i] * I[i] * ntaps[i] < (1LL << 31), "pack_weights_multi: tensor %d too large", i);
+    }
+    auto tiled = [&](int i) { return modes[i] <= 1 && ntaps[i] <= 36; };
+    // conv weights: tiled kernel, the forward and dgrad images of one source share a table entry
+    {
+        MTPackTileTable tb; tb.n = 0; int nb = 0;
+        auto flush = [&]() -> int {
+            if (tb.n == 0) return 0;
+            if (dtype == UNET_BF16) hipLaunchKernelGGL((mt_pack_tile_kernel<__bf16>), dim3(nb), dim3(256), 0, s, tb);
+            else hipLaunchKernelGGL((mt_pack_tile_kernel<float>), dim3(nb), dim3(256), 0, s, tb);
+            UNET_LAUNCH_CHECK();
+            tb.n = 0; nb = 0;
+            return 0;
+        };
+        for (int i = 0; i < nt; ++i) {
+            if (!tiled(i)) continue;
+            int e = -1;
+            for (int j = 0; j < tb.n; ++j)
+                if (tb.src[j] == (const float*)src[i] && tb.O[j] == O[i] && tb.I[j] == I[i] && tb.NT[j] == ntaps[i] &&
+                    (modes[i] == 0 ? tb.dst0[j] : tb.dst1[j]) == nullptr) { e = j; break; }
+            if (e < 0) {
+                if (tb.n == MT_MAX) { int rc = flush(); if (rc) return rc; }
+                e = tb.n++;
+                nb += pack_tiles(O[i], I[i], ntaps[i]);
+                tb.blk_end[e] = nb; tb.src[e] = (const float*)src[i]; tb.dst0[e] = nullptr; tb.dst1[e] = nullptr;
+                tb.O[e] = O[i]; tb.I[e] = I[i]; tb.NT[e] = ntaps[i];
+            }
+            (modes[i] == 0 ? tb.dst0[e] : tb.dst1[e]) = dst[i];
+        }
+        int rc = flush(); if (rc) return rc;
+    }
+    // transposed-conv images (and anything the tile does not hold): per-element gather
     for (int i0 = 0; i0 < nt;) {
         MTPackTable tb; tb.n = 0; int nb = 0;
         for (; i0 < nt && tb.n < MT_MAX; ++i0) {
-            UNET_CHECK(modes[i0] >= 0 && modes[i0] <= 3, "bad pack mode %d", modes[i0]);
-            if (modes[i0] >= 2) UNET_CHECK(ntaps[i0] == 4, "convT pack needs 4 taps");
-            UNET_CHECK(src[i0] && dst[i0] && O[i0] > 0 && I[i0] > 0 && ntaps[i0] > 0, "pack_weights_multi: bad tensor %d", i0);
+            if (tiled(i0)) continue;
             nb += mt_chunks((long long)O[i0] * I[i0] * ntaps[i0]);
             tb.blk_end[tb.n] = nb; tb.src[tb.n] = (const float*)src[i0]; tb.dst[tb.n] = dst[i0];
             tb.mode[tb.n] = modes[i0]; tb.O[tb.n] = O[i0]; tb.I[tb.n] = I[i0]; tb.NT[tb.n] = ntaps[i0]; ++tb.n;
