@@ -7,7 +7,7 @@
   bf16 mode : stated tolerance: logits rel-L2 <= 3e-2, loss <= 2e-2 relative, argmax agreement >= 98 %
               against the fp32 reference golden.  Gradients: this network amplifies storage-rounding noise
               layer by layer on the way back (train-mode BN + ReLU at random init; even fp32-vs-fp64 is 1e-3
-              at the deepest layers, see tools/bf16_diag2.py), so a fixed bound would be meaningless.  The
+              at the deepest layers, see tests/diag_bf16_precision.py), so a fixed bound would be meaningless.  The
               bound is relative to a CPU emulation of the same storage precision: per tensor,
               relL2(hip_bf16, fp32 ref) <= 1.6 * relL2(oracle with bf16 rounding at the same points, fp32 ref) + 1e-2.
 """
