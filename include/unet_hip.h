@@ -78,7 +78,9 @@ int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, i
 /* fp32 master weights -> packed compute-dtype images.  mode 0 conv fwd, 1 conv dgrad (flipped,
  * transposed), 2 convT fwd, 3 convT dgrad.  O,I = dims 0,1 of the source tensor. */
 int unet_pack_weights(int dtype, int mode, const float* src, void* dst, int O, int I, int ntaps, void* stream);
-/* The same for n tensors in one launch per 40 tensors (HOST arrays; they travel as kernel arguments). */
+/* The same for n tensors in one launch per 40 tensors (HOST arrays; they travel as kernel arguments).  Conv images
+ * (modes 0/1) go through an LDS tile that reads each source row segment once; entries that share `src` (the forward
+ * and dgrad image of one weight) are served by the same pass. */
 int unet_pack_weights_multi(int dtype, int nt, const int* modes, const void* const* src, void* const* dst,
                             const int* O, const int* I, const int* ntaps, void* stream);
 
