@@ -57,7 +57,7 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // GEN = false: the specialised kernel of the U-Net shapes (channel counts multiples of the tile, output
 // a whole number of 16x32 tiles, plain store, split point on a 64-channel boundary); GEN = true: the
 // same pipeline with every bound checked per lane and the accumulate / ReLU / arbitrary-split stores.
-template <int WC, bool GEN>
+template <int WC, bool GEN, bool DST = false>
 __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC>;
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
@@ -282,7 +282,21 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     const bool late = !ASYM && wave >= 4;
     int late_ph = -1;          // the refill waves 4-7 still owe (-1: none)
     bool h_owed = false;       // waves 0-3, one-phase chunks: the halo request held back until after the epilogue
+    // DEFERRED STATISTICS (64-channel tiles of the specialised kernel: one channel block, so every tile of this
+    // workgroup covers the same 64 channels).  The lane keeps its (sum, sum of squares) partials in registers across
+    // tiles; the 16-lane reduction, the cross-wave reduction and its two barriers run once, on the workgroup's LAST
+    // tile, whose stats row then carries the whole workgroup's sums - the rows of its other tiles are written as
+    // zeros, so "sum over rows" (all any consumer does with them) is unchanged.  Per tile this removes 32 DPP
+    // reductions per wave and two barriers: the forward epilogue of these HBM-bound layers was 2.4x the dgrad one.
+    constexpr bool DEFER = DST;      // own instantiation: the 32 extra live registers cost the launches without statistics 6 %
+    static_assert(!DST || (!GEN && WC == 1), "deferred statistics are for the specialised 64-channel kernel");
+    float run1[DEFER ? 4 : 1][4], run2[DEFER ? 4 : 1][4];
+#pragma unroll
+    for (int i = 0; i < (DEFER ? 4 : 1); ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { run1[i][r] = 0.f; run2[i][r] = 0.f; }
     for (;;) {
+        const bool last_tile = tile_i + (int)gridDim.x >= total_tiles;
         f32x4 acc[4][NPG];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // pass 1 (forward only): BN partial statistics.  Every lane stores its (sum, sum of squares) pair:
                 // lanes other than the group's first aim at a scratch slot, which is cheaper than sixteen exec-mask
                 // round trips.
-                if (do_stats) {
+                if (do_stats && (!DEFER || last_tile)) {
                     // one address select per lane; the 16 pairs then go to base + immediate (the scratch slots of
                     // different lanes overlap, which is fine for values nobody reads, and stay on distinct banks)
                     char* sbase = l15e == 0 ? (char*)&red[(wr * BCO + wc * 64 + 4 * ge) * 2]
@@ -395,6 +409,10 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
                         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (DEFER) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { s1[r] = run1[ct][r]; s2[r] = run2[ct][r]; }
+                        }
 #pragma unroll
                         for (int pg = 0; pg < NPG; ++pg)
 #pragma unroll
@@ -407,6 +425,16 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                             *(float2*)(sbase + (ct * 16 + r) * 8) = t;
                         }
                     }
+                } else if (DEFER && do_stats) {
+#pragma unroll
+                    for (int ct = 0; ct < (DEFER ? 4 : 1); ++ct)
+#pragma unroll
+                        for (int pg = 0; pg < NPG; ++pg)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float v = acc[ct][pg][r];
+                                run1[ct][r] += v; run2[ct][r] = fmaf(v, v, run2[ct][r]);
+                            }
                 }
                 // pass 2: every 16-pixel group goes through a wave-private LDS tile [16 px][64 co] (16-byte
                 // slots XORed with px & 7) and leaves as two stores of 8 pixels x 128 contiguous bytes:
@@ -498,7 +526,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         };
         epilogue(std::integral_constant<bool, fast>{});
         if (h_owed) { push_h(); h_owed = false; }
-        if (do_stats) {
+        if (DEFER && do_stats && !last_tile) {
+            if (tid < BCO * 2) a.stats[((size_t)cur.pt * a.Cout + (tid >> 1)) * 2 + (tid & 1)] = 0.f;      // this tile's sums ride in the last row
+        } else if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
                 const int ch = tid >> 1, k = tid & 1;
@@ -519,12 +549,12 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #endif
 }
 
-template <int WC, bool GEN>
+template <int WC, bool GEN, bool DST = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC>;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC, GEN>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC, GEN, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
         attr_done = true;
     }
@@ -534,7 +564,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -548,5 +578,6 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     const bool gen = (a.Cin & 31) != 0 || (a.Cout % bco) != 0 || (a.Hout & 15) != 0 || (a.Wout & 31) != 0 ||
                      (a.flags & 1) != 0 || (a.csplit & 63) != 0;
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
-    return gen ? launch_conv2<1, true>(a, s) : launch_conv2<1, false>(a, s);
+    if (gen) return launch_conv2<1, true>(a, s);
+    return a.stats != nullptr ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false>(a, s);
 }
