@@ -33,7 +33,8 @@ const char* unet_last_error(void);
  * (epi=1: 1x1 GEMM + 2x2 pixel shuffle straight into the concat buffer, models/unet.py:35,53,59)
  * and its dgrad (kh=2,kw=1,stride_h=2 on the [N,2H,W,2C] view of the output gradient).
  * w: packed [kh*kw][Cout][Cin] (unet_pack_weights).  bias/stats may be NULL.  stats receives
- * unet_conv_tiles() rows of [Cout][2] = per-tile (sum, sum of squares) of the fp32 outputs. */
+ * unet_conv_tiles() rows of [Cout][2] = partial (sum, sum of squares) of the fp32 outputs; only the
+ * sum over the rows is defined (a row may carry several tiles' sums and others zeros). */
 int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout);
 int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                   const void* x, const void* w, const float* bias, void* y, float* stats,
