@@ -121,3 +121,19 @@ void unet_set_error(const char* fmt, ...);
             return -2;                                                             \
         }                                                                          \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: remember per kernel instantiation
+// which devices already have it (bit d = device d), so a process that drives several GPUs gets it on each of them.
+// Thread-safe: two threads may both set the attribute once, which is harmless.
+#include <atomic>
+struct DynLdsOnce { std::atomic<unsigned long long> devices{0}; };
+static inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { unet_set_error("hipGetDevice failed"); return -2; }
+    if (dev >= 0 && dev < 64 && ((once.devices.load(std::memory_order_relaxed) >> dev) & 1ull)) return 0;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d bytes of LDS) failed on device %d: %s", bytes, dev, hipGetErrorString(e)); return -2; }
+    if (dev >= 0 && dev < 64) once.devices.fetch_or(1ull << dev, std::memory_order_relaxed);
+    return 0;
+}
+

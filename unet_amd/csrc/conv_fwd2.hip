@@ -552,12 +552,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 template <int WC, bool GEN, bool DST = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_v2_kernel<WC, GEN, DST>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
-        attr_done = true;
-    }
+    static DynLdsOnce lds_once;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;

@@ -208,12 +208,8 @@ __global__ __launch_bounds__(512) void convT2_kernel(CT2Args a, FastDiv d_n, Fas
 
 template <bool DGRAD>
 static int launch_convT2(CT2Args a, hipStream_t stream) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)convT2_kernel<DGRAD>, hipFuncAttributeMaxDynamicSharedMemorySize, CT2Cfg::SMEM);
-        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", CT2Cfg::SMEM, hipGetErrorString(e)); return -2; }
-        attr_done = true;
-    }
+    static DynLdsOnce lds_once;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)convT2_kernel<DGRAD>, CT2Cfg::SMEM)) return rc;
     a.tiles_h = a.H / 16; a.tiles_w = a.W / 32;
     a.ntile_n = (DGRAD ? a.Ci : 4 * a.Co) / 128;
     a.total_tiles = a.N * a.tiles_h * a.tiles_w * a.ntile_n;

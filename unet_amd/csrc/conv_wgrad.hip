@@ -200,13 +200,8 @@ static int launch_wgrad(const WgradArgs& a, hipStream_t stream, int nsplit) {
     constexpr int TG = KH * KW;
     constexpr int HH = 7 * SH + KH, HWD = 31 + KW;
     constexpr int SMEM = 8 * 32 * 128 + HH * HWD * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, KH, KW, SH, TG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", SMEM, hipGetErrorString(e)); return -2; }
-        attr_done = true;
-    }
+    static DynLdsOnce lds_once;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad_kernel<T, KH, KW, SH, TG>, SMEM)) return rc;
     constexpr int CT = WG<T>::CT;
     dim3 grid((unsigned)nsplit, (unsigned)((a.Cout + CT - 1) / CT), (unsigned)((a.Cin + CT - 1) / CT));
     hipLaunchKernelGGL((conv_wgrad_kernel<T, KH, KW, SH, TG>), grid, dim3(256), SMEM, stream, a);

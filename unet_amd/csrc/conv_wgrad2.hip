@@ -313,13 +313,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
 template <int KH, int KW, int SH, int WT, int TH, bool GEN>
 static int launch_wgrad2g(WgradArgs a, hipStream_t stream, int nsplit) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        if (e != hipSuccess) { unet_set_error("hipFuncSetAttribute(%d) failed: %s", C::SMEM, hipGetErrorString(e)); return -2; }
-        attr_done = true;
-    }
+    static DynLdsOnce lds_once;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + TH - 1) / TH; a.tiles_w = (a.Wout + 31) / 32;
     a.tiles_total = a.N * a.tiles_h * a.tiles_w;
     a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
