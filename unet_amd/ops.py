@@ -320,6 +320,8 @@ def conv_first_wgrad(dz: Act, x: torch.Tensor, kh: int, kw: int, ws: Workspace) 
     Cout = dz.C
     if dz.off != 0 or dz.ld != Cout or (dz.N, dz.H, dz.W) != (N, H, W):
         raise UNetHipError("first conv wgrad: bad gradient layout")
+    if Cout * kh * kw > ws.acc.numel():
+        raise UNetHipError("first conv wgrad: workspace too small for Cout * taps accumulators")
     dw = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
     check(lib().unet_conv_first_wgrad(dz.dt, kh, kw, _p(dz.buf), _p(x), _p(dw), N, H, W, Cin, Cout, _p(ws.acc), _stream()),
           "conv_first_wgrad")
@@ -467,6 +469,8 @@ def channel_sum(x: Act, ws: Workspace, out: Optional[torch.Tensor] = None, accum
     x.check()
     if out is None:
         out = torch.empty((x.C,), dtype=torch.float32, device=x.buf.device)
+    if x.C > ws.acc.numel() or out.numel() != x.C:
+        raise UNetHipError("channel_sum: workspace or output too small")
     check(lib().unet_channel_sum(x.dt, _p(x.buf), x.ld, x.off, x.M, x.C, _p(out), 1 if accumulate else 0, _p(ws.acc), _stream()),
           "channel_sum")
     return out
