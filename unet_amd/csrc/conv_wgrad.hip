@@ -246,6 +246,7 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
                                int Hout, int Wout, int Cout, int lddz, int dzoff,
                                int pad_h, int pad_w, void* stream) {
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    UNET_CHECK(dz != nullptr && x != nullptr && slab != nullptr, "conv_wgrad: null pointer argument");      // dw may be NULL: partials stay in the slab
     UNET_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddz % 8 == 0 && dzoff % 8 == 0,
                "channel counts/strides/offsets must be multiples of 8");
     UNET_CHECK(xoff + Cin <= ldx && dzoff + Cout <= lddz, "channel slice exceeds pixel stride");
