@@ -75,7 +75,7 @@ def pmc_traffic():
         return None
 
 
-def cpu_baseline(sample_images=2, size=512, iters=2):
+def cpu_baseline(sample_images=4, size=512, iters=3):
     """Oracle fwd + loss + bwd on the host cores (fp32), bounded sample of the same workload."""
     from oracle import loss_ref, unet_ref
     from unet_amd.models import UNet
