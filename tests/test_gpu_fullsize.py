@@ -89,6 +89,28 @@ def test_split_destination_dgrad_full_size(dev):
     torch.testing.assert_close(sums[:64], ref, rtol=1e-5, atol=1e-2)
     torch.testing.assert_close(sums[64:], 2 * ref, rtol=1e-5, atol=1e-2)
 
+@pytest.mark.parametrize("level", [(64, 512), (128, 256), (64, 48)])
+def test_conv_statistics_rows_sum_to_the_channel_sums(dev, level):
+    """The BN partial statistics of the conv epilogue at full size: with a one-hot centre tap the output is the input
+    (exact in bf16), so sum over the rows must equal the per-channel sum / sum of squares of the input.  (64, 512) runs
+    the deferred path with 64 tiles per workgroup (one row per workgroup carries its sums, the others are zero);
+    (64, 48) has fewer tiles than workgroups."""
+    ops = ops_mod()
+    C, H = level
+    n = N if H > 48 else 2
+    x = rand_act(ops, n, H, H, C, dev, 11)
+    w = torch.zeros((C, C, 3, 3), device=dev)
+    idx = torch.arange(C, device=dev)
+    w[idx, idx, 1, 1] = 1.0
+    y = ops.dense(n, H, H, C, ops.BF16, dev)
+    bias = torch.zeros(C, device=dev)
+    rows = ops.conv_fwd(x, ops.pack_weights(w, 0, ops.BF16), bias, y, 3, 3, C, C, stats=True)
+    assert torch.equal(y.buf, x.buf)
+    xx = x.buf.double()
+    got = rows.double().sum(0)
+    torch.testing.assert_close(got[:, 0], xx.sum((0, 1, 2)), rtol=2e-5, atol=2e-2)
+    torch.testing.assert_close(got[:, 1], (xx * xx).sum((0, 1, 2)), rtol=2e-5, atol=2e-2)
+
 
 @pytest.mark.parametrize("level", [(64, 512), (128, 256), (512, 64)])
 def test_weight_gradient_of_ones_counts_positions(dev, level):
