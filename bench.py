@@ -123,6 +123,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     use_dist = world > 1 or args.force_dist
+    if args.force_dist:
+        os.environ["UNET_AMD_DP_FORCE_COLLECTIVES"] = "1"      # the one-rank rehearsal still launches the RCCL collectives
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

@@ -11,6 +11,7 @@ DistributedDataParallel wrap (/root/reference/train.py:139-144).
     finish_grad_sync() (called by step_batch before clipping) waits and scatters the averages into
     p.grad.  xGMI is point-to-point, so buckets are large (default 32 MiB: 4 all-reduces per step).
 """
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -26,6 +27,8 @@ class BucketReducer:
         self.bucket_bytes = int(bucket_bytes)
         self.comm_dtype = comm_dtype
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # rehearsal on one GPU: issue the collectives even in a one-rank group (UNET_AMD_DP_FORCE_COLLECTIVES=1)
+        self.collective = dist.is_initialized() and (self.world > 1 or os.environ.get("UNET_AMD_DP_FORCE_COLLECTIVES") == "1")
         self._pending: List = []          # (names, shapes, flat, work)
         self._cur_names: List[str] = []
         self._cur: List[torch.Tensor] = []
@@ -48,7 +51,7 @@ class BucketReducer:
         dtype = self.comm_dtype or self._cur[0].dtype
         flat = torch.cat([t.reshape(-1).to(dtype) for t in self._cur])
         work = None
-        if self.world > 1:
+        if self.collective:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._pending.append((self._cur_names, [t.shape for t in self._cur], flat, work))
         self._cur_names, self._cur, self._cur_bytes = [], [], 0
@@ -87,7 +90,8 @@ class DataParallel(nn.Module):
         self.reducer = BucketReducer(process_group, int(bucket_cap_mb * (1 << 20)), comm_dtype)
         self._params = dict(module.named_parameters())
         module._grad_hook = self.reducer.add
-        if self.world > 1:
+        self.collective = self.reducer.collective
+        if self.collective:
             self._broadcast([p.data for p in module.parameters()])
             self._broadcast([b.data for b in module.buffers()])
 
@@ -106,7 +110,7 @@ class DataParallel(nn.Module):
             torch._foreach_copy_(ts, views)          # one multi-tensor kernel, not one copy per buffer
 
     def forward(self, *args, **kwargs):
-        if self.world > 1 and self.broadcast_buffers and self.module.training:
+        if self.collective and self.broadcast_buffers and self.module.training:
             self._broadcast([b.data for b in self.module.buffers()])
         return self.module(*args, **kwargs)
 
