@@ -57,6 +57,20 @@ def _worker(rank, world, port, q):
             parts = [torch.zeros_like(local[n]) for _ in range(world)]
             dist.all_gather(parts, local[n])
             ok = ok and torch.allclose(p.grad, sum(parts) / world, atol=1e-6)
+        # --- BN buffers: per-rank statistics after a training forward; rank 0's again at the next forward's sync,
+        #     broadcast in place through the flat tensors the buffers are views of
+        def flat_bufs():
+            return torch.cat([b.reshape(-1).float() for b in net.buffers()])
+        parts = [torch.zeros_like(flat_bufs()) for _ in range(world)]
+        dist.all_gather(parts, flat_bufs())
+        ok = ok and not torch.equal(parts[0], parts[1])          # different inputs -> different running statistics
+        ok = ok and dp._buffers_are_views()
+        dp._sync_buffers()                                        # what the next training forward does first
+        ok = ok and torch.equal(flat_bufs(), parts[0])
+        net[1].running_mean.data = net[1].running_mean.data.clone() + (1.0 if rank else 0.0)    # storage replaced (as .to() does)
+        ok = ok and not dp._buffers_are_views()
+        dp._sync_buffers()                                        # re-flattens, then broadcasts
+        ok = ok and dp._buffers_are_views() and torch.equal(flat_bufs(), parts[0])
         # --- sharding: rank r takes samples r::W of the epoch permutation, like DistributedSampler
         from torch.utils.data import DistributedSampler
         ds = list(range(10))

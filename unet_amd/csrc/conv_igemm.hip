@@ -297,7 +297,6 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
     if (csplit > 0) UNET_CHECK(y2 != nullptr && csplit % 8 == 0 && ldy2 % 8 == 0 && yoff2 % 8 == 0 && epi == 0 && csplit < Cout,
                                "bad split-output arguments");
-    UNET_CHECK(x != nullptr && w != nullptr && y != nullptr, "conv_fwd: null pointer argument");
     UNET_CHECK(N > 0 && Hin > 0 && Win > 0 && Hout > 0 && Wout > 0, "empty conv problem");
     UNET_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0,
                "channel counts/strides/offsets must be multiples of 8 (Cin=%d Cout=%d ldx=%d xoff=%d ldy=%d yoff=%d)",
@@ -308,6 +307,7 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     // the output grid the tiles cover must be what the kernel geometry produces
     const int eh = (Hin + 2 * pad_h - kh) / stride_h + 1, ew = Win + 2 * pad_w - kw + 1;
     UNET_CHECK(eh == Hout && ew == Wout, "output %dx%d does not match conv geometry %dx%d", Hout, Wout, eh, ew);
+    UNET_CHECK(x != nullptr && w != nullptr && y != nullptr, "conv_fwd: null pointer argument");
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
     a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.ldx = ldx; a.xoff = xoff;

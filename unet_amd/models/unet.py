@@ -94,6 +94,10 @@ class _UNetFn(torch.autograd.Function):
         hook = getattr(module, "_grad_hook", None)
         grads = module._engine.backward(dlogits, ctx.P, sv, hook)
         ctx.sv = None
+        flush = getattr(module, "_grad_flush", None)
+        if flush is not None:
+            flush()          # data parallel: the last partial bucket leaves now, and drops its references to the gradients,
+                             # so autograd takes them over below instead of cloning each one
         out = []
         for n in ctx.names:
             p = ctx.P[n]

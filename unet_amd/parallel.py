@@ -57,6 +57,10 @@ class BucketReducer:
         self._cur_names, self._cur, self._cur_bytes = [], [], 0
         self.buckets_launched += 1
 
+    def flush(self):
+        """All gradients of this backward pass have been handed over: launch the partial last bucket."""
+        self._launch()
+
     def finish(self) -> Dict[str, torch.Tensor]:
         """Wait for every bucket; returns {name: averaged gradient view}."""
         self._launch()
@@ -87,31 +91,71 @@ class DataParallel(nn.Module):
         self.pg = process_group
         self.broadcast_buffers = broadcast_buffers
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        bucket_cap_mb = float(os.environ.get("UNET_AMD_DP_BUCKET_MB", bucket_cap_mb))       # experiments: 1e9 = one all-reduce after backward
         self.reducer = BucketReducer(process_group, int(bucket_cap_mb * (1 << 20)), comm_dtype)
         self._params = dict(module.named_parameters())
         module._grad_hook = self.reducer.add
+        module._grad_flush = self.reducer.flush
         self.collective = self.reducer.collective
+        self._buf_flats: List = []          # [(flat tensor, [buffers that are views of it])] per dtype
         if self.collective:
             self._broadcast([p.data for p in module.parameters()])
-            self._broadcast([b.data for b in module.buffers()])
+            self._sync_buffers()
+
+    def _src(self):
+        return dist.get_global_rank(self.pg, 0) if self.pg is not None else 0
 
     def _broadcast(self, tensors: List[torch.Tensor]):
-        """rank 0 -> all, coalesced per dtype into one flat message."""
+        """rank 0 -> all, coalesced per dtype into one flat message (wrap time only)."""
         by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
         for t in tensors:
             by_dtype.setdefault(t.dtype, []).append(t)
         for ts in by_dtype.values():
             flat = torch.cat([t.reshape(-1) for t in ts])
-            dist.broadcast(flat, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
-            off, views = 0, []
+            dist.broadcast(flat, src=self._src(), group=self.pg)
+            off = 0
             for t in ts:
-                views.append(flat[off:off + t.numel()].view_as(t))
+                t.copy_(flat[off:off + t.numel()].view_as(t))
                 off += t.numel()
-            torch._foreach_copy_(ts, views)          # one multi-tensor kernel, not one copy per buffer
+
+    # The BN buffers are re-broadcast before EVERY training forward (DDP's broadcast_buffers=True), so they are kept as
+    # views of one flat tensor per dtype: the broadcast then runs in place on that tensor, with no gather copy before
+    # and no scatter copies after it (54 buffers for the 4-level U-Net).
+    def _flatten_buffers(self):
+        self._buf_flats = []
+        by_dtype: Dict[tuple, List[torch.Tensor]] = {}
+        for b in self.module.buffers():
+            if b is not None and b.is_contiguous():
+                by_dtype.setdefault((b.dtype, b.device), []).append(b)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            off = 0
+            for t in ts:
+                t.data = flat[off:off + t.numel()].view(t.shape)
+                off += t.numel()
+            self._buf_flats.append((flat, ts))
+
+    def _buffers_are_views(self) -> bool:
+        """False after .to() / load_state_dict(assign=True) / new buffers: the module's buffers left the flat tensors."""
+        n = 0
+        for flat, ts in self._buf_flats:
+            base, esz, off = flat.data_ptr(), flat.element_size(), 0
+            for t in ts:
+                if t.data_ptr() != base + off * esz or t.device != flat.device:
+                    return False
+                off += t.numel()
+            n += len(ts)
+        return n == sum(1 for b in self.module.buffers() if b is not None and b.is_contiguous())
+
+    def _sync_buffers(self):
+        if not self._buf_flats or not self._buffers_are_views():
+            self._flatten_buffers()
+        for flat, _ in self._buf_flats:
+            dist.broadcast(flat, src=self._src(), group=self.pg)
 
     def forward(self, *args, **kwargs):
         if self.collective and self.broadcast_buffers and self.module.training:
-            self._broadcast([b.data for b in self.module.buffers()])
+            self._sync_buffers()
         return self.module(*args, **kwargs)
 
     def finish_grad_sync(self):
