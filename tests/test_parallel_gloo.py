@@ -71,6 +71,15 @@ def _worker(rank, world, port, q):
         ok = ok and not dp._buffers_are_views()
         dp._sync_buffers()                                        # re-flattens, then broadcasts
         ok = ok and dp._buffers_are_views() and torch.equal(flat_bufs(), parts[0])
+        # --- the flattened buffers still save and load like ordinary ones (torch.save keeps the shared storage once)
+        import io
+        f = io.BytesIO()
+        torch.save(dp.state_dict(), f)
+        f.seek(0)
+        back = torch.load(f, weights_only=True)
+        ok = ok and all(torch.equal(back[k], v) for k, v in dp.state_dict().items())
+        dp.load_state_dict(back)
+        ok = ok and dp._buffers_are_views()                       # load_state_dict copies in place
         # --- sharding: rank r takes samples r::W of the epoch permutation, like DistributedSampler
         from torch.utils.data import DistributedSampler
         ds = list(range(10))
