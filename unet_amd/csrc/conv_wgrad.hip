@@ -195,6 +195,48 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
+// The same for a 9-tap gradient.  A thread owns one (o, i) pair and all nine taps: nine independent coalesced loads per
+// split, and its nine results leave as 36 contiguous bytes.  Small layers have few (o, i) pairs but many splits (64 x 64
+// weights: 4096 pairs, 256 splits = 16 workgroups walking 256 slabs each), so KL lanes share a pair: lane kl sums splits
+// kl, kl + KL, ... in order, lane 0 then adds the KL partials in lane order - a fixed order, bitwise reproducible.
+template <int KL>
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* __restrict__ slab, float* __restrict__ out,
+                                                            int nsplit, int O, int I, int accumulate, int out_taps, int out_tap0) {
+    constexpr int EL = 256 / KL;                         // (o, i) pairs per workgroup
+    __shared__ float part[KL > 1 ? KL : 1][EL][9];
+    const size_t OI = (size_t)O * I, total = 9 * OI;
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+    for (size_t e0 = (size_t)blockIdx.x * EL; e0 < OI; e0 += (size_t)gridDim.x * EL) {
+        const size_t e = e0 + el;
+        float s[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s[t] = 0.f;
+        if (e < OI) {
+            for (int k = kl; k < nsplit; k += KL) {
+                const float* p = slab + (size_t)k * total + e;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s[t] += p[(size_t)t * OI];
+            }
+        }
+        if (KL > 1) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) part[kl][el][t] = s[t];
+            __syncthreads();
+            if (kl == 0) {
+                for (int q = 1; q < KL; ++q)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) s[t] += part[q][el][t];
+            }
+            __syncthreads();
+        }
+        if (kl == 0 && e < OI) {
+            float* d = out + e * out_taps + out_tap0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d[t] = accumulate ? d[t] + s[t] : s[t];
+        }
+    }
+}
+
 template <typename T, int KH, int KW, int SH>
 static int launch_wgrad(const WgradArgs& a, hipStream_t stream, int nsplit) {
     constexpr int TG = KH * KW;
@@ -273,7 +315,19 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
     const size_t total = (size_t)kh * kw * Cout * Cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, nsplit, kh * kw, Cout, Cin, accumulate, dw_taps, dw_tap0);
+    if (kh * kw == 9) {
+        const size_t OI = (size_t)Cout * Cin;
+        if (OI < 262144 && nsplit >= 16) {                // fewer than 1024 workgroups of pairs: share each pair among 8 lanes
+            int b9 = (int)((OI + 31) / 32);
+            hipLaunchKernelGGL(wgrad_reduce9_kernel<8>, dim3(b9), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
+        } else {
+            int b9 = (int)((OI + 255) / 256);
+            if (b9 > 4096) b9 = 4096;
+            hipLaunchKernelGGL(wgrad_reduce9_kernel<1>, dim3(b9), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
+        }
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, nsplit, kh * kw, Cout, Cin, accumulate, dw_taps, dw_tap0);
+    }
     UNET_LAUNCH_CHECK();
     return 0;
 }
