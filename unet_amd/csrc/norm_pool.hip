@@ -53,17 +53,15 @@ __global__ void bn_stats_reduce_kernel(const float* __restrict__ rows, int nrows
 
 // One thread per channel: batch mean / biased var -> (scale, shift, mean, invstd) and the running
 // statistics update r = (1-m) r + m stat with UNBIASED variance, num_batches_tracked += 1.
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, double count, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ nbt, float momentum, float eps,
-                                   float* __restrict__ scale, float* __restrict__ shift,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bn_finalize_channel(int c, double sum, double sumsq, double count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                    long long* __restrict__ nbt, float momentum, float eps,
+                                                    float* __restrict__ scale, float* __restrict__ shift,
+                                                    float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     if (c == 0 && nbt != nullptr) *nbt += 1;
-    if (c >= C) return;
-    const double mean = acc[c * 2] / count;
-    double var = acc[c * 2 + 1] / count - mean * mean;
+    const double mean = sum / count;
+    double var = sumsq / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * invstd;
@@ -75,6 +73,48 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, double count,
         const double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, double count, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ nbt, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    bn_finalize_channel(c, acc[c * 2], acc[c * 2 + 1], count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                        scale, shift, mean_out, invstd_out);
+}
+
+// Few rows (the deep layers: <= 1024 pixel tiles): one launch instead of memset + reduce + finalize.  A workgroup owns
+// 32 channels, its 8 row lanes walk all rows, the partials are added in lane order (no atomics: deterministic) and the
+// channel's first lane finalizes.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ rows, int nrows, int C, double count,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                long long* __restrict__ nbt, float momentum, float eps,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+    const int ch = threadIdx.x & 31, pl = threadIdx.x >> 5;     // 32 channels x 8 row lanes
+    const int c = blockIdx.x * 32 + ch;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int r = pl; r < nrows; r += 8) {
+            const float2 v = *(const float2*)(rows + ((size_t)r * C + c) * 2);
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+    }
+    __shared__ double red[8][32][2];
+    red[pl][ch][0] = s1;
+    red[pl][ch][1] = s2;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+        for (int p = 0; p < 8; ++p) { a += red[p][ch][0]; b += red[p][ch][1]; }
+        bn_finalize_channel(c, a, b, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean_out, invstd_out);
     }
 }
 
@@ -508,6 +548,12 @@ extern "C" int unet_bn_finalize(const float* stat_rows, int nrows, int C, long l
                                 double* acc_ws /* 2*C doubles */, void* stream) {
     UNET_CHECK(nrows > 0 && C > 0 && count > 0, "bn_finalize: empty problem");
     hipStream_t s = (hipStream_t)stream;
+    if (nrows <= 1024) {
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, stat_rows, nrows, C, (double)count, gamma, beta,
+                           running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
+        UNET_LAUNCH_CHECK();
+        return 0;
+    }
     if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 2 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
     int S = (nrows + 63) / 64; if (S > 64) S = 64; if (S < 1) S = 1;
     hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((C + 31) / 32, S), dim3(256), 0, s, stat_rows, nrows, C, acc_ws);
