@@ -89,31 +89,42 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, double count,
 }
 
 // Few rows (the deep layers: <= 1024 pixel tiles): one launch instead of memset + reduce + finalize.  A workgroup owns
-// 32 channels, its 8 row lanes walk all rows, the partials are added in lane order (no atomics: deterministic) and the
-// channel's first lane finalizes.
+// 8 channels (one 64-byte run per row), its 32 row lanes walk all rows, the partials are added in lane order (no atomics:
+// deterministic) and the channel's first lane finalizes.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ rows, int nrows, int C, double count,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                 long long* __restrict__ nbt, float momentum, float eps,
                                                                 float* __restrict__ scale, float* __restrict__ shift,
                                                                 float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-    const int ch = threadIdx.x & 31, pl = threadIdx.x >> 5;     // 32 channels x 8 row lanes
-    const int c = blockIdx.x * 32 + ch;
+    const int ch = threadIdx.x & 7, pl = threadIdx.x >> 3;      // 8 channels x 32 row lanes
+    const int c = blockIdx.x * 8 + ch;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int r = pl; r < nrows; r += 8) {
-            const float2 v = *(const float2*)(rows + ((size_t)r * C + c) * 2);
-            s1 += (double)v.x;
-            s2 += (double)v.y;
+        const float* col = rows + (size_t)c * 2;
+        int r = pl;
+        for (; r + 96 < nrows; r += 128) {                      // four independent loads in flight
+            const float2 v0 = *(const float2*)(col + (size_t)r * C * 2);
+            const float2 v1 = *(const float2*)(col + (size_t)(r + 32) * C * 2);
+            const float2 v2 = *(const float2*)(col + (size_t)(r + 64) * C * 2);
+            const float2 v3 = *(const float2*)(col + (size_t)(r + 96) * C * 2);
+            s1 += (double)v0.x; s2 += (double)v0.y;
+            s1 += (double)v1.x; s2 += (double)v1.y;
+            s1 += (double)v2.x; s2 += (double)v2.y;
+            s1 += (double)v3.x; s2 += (double)v3.y;
+        }
+        for (; r < nrows; r += 32) {
+            const float2 v = *(const float2*)(col + (size_t)r * C * 2);
+            s1 += (double)v.x; s2 += (double)v.y;
         }
     }
-    __shared__ double red[8][32][2];
+    __shared__ double red[32][8][2];
     red[pl][ch][0] = s1;
     red[pl][ch][1] = s2;
     __syncthreads();
     if (pl == 0 && c < C) {
         double a = 0.0, b = 0.0;
-        for (int p = 0; p < 8; ++p) { a += red[p][ch][0]; b += red[p][ch][1]; }
+        for (int p = 0; p < 32; ++p) { a += red[p][ch][0]; b += red[p][ch][1]; }
         bn_finalize_channel(c, a, b, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean_out, invstd_out);
     }
 }
@@ -549,7 +560,7 @@ extern "C" int unet_bn_finalize(const float* stat_rows, int nrows, int C, long l
     UNET_CHECK(nrows > 0 && C > 0 && count > 0, "bn_finalize: empty problem");
     hipStream_t s = (hipStream_t)stream;
     if (nrows <= 1024) {
-        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, stat_rows, nrows, C, (double)count, gamma, beta,
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, s, stat_rows, nrows, C, (double)count, gamma, beta,
                            running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
         UNET_LAUNCH_CHECK();
         return 0;
