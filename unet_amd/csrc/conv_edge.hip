@@ -438,14 +438,31 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, T* __restrict
 }
 
 // convT weight-grad slab [nsplit][tap=i2][Ci][2*Co] -> dW (Ci,Co,2,2)
-__global__ void convT_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int Ci, int Co) {
+// KL lanes share an element: lane kl sums splits kl, kl + KL, ... in order, lane 0 adds the KL partials in lane order (fixed
+// order, bitwise reproducible).  The top decoder level has 32768 elements but 256 splits: 8 lanes per element there.
+template <int KL>
+__global__ __launch_bounds__(256) void convT_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int nsplit, int Ci, int Co) {
+    constexpr int EL = 256 / KL;
+    __shared__ float part[KL][EL];
     const size_t total = (size_t)2 * Ci * 2 * Co;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
+    for (size_t e0 = (size_t)blockIdx.x * EL; e0 < total; e0 += (size_t)gridDim.x * EL) {
+        const size_t e = e0 + el;
         float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * total + e];
-        const int cc = (int)(e % (2 * Co)); const size_t r = e / (2 * Co); const int ci = (int)(r % Ci); const int i2 = (int)(r / Ci);
-        const int j2 = cc / Co, c = cc - j2 * Co;
-        out[((size_t)ci * Co + c) * 4 + i2 * 2 + j2] = s;
+        if (e < total)
+            for (int k = kl; k < nsplit; k += KL) s += slab[(size_t)k * total + e];
+        if (KL > 1) {
+            part[kl][el] = s;
+            __syncthreads();
+            if (kl == 0)
+                for (int q = 1; q < KL; ++q) s += part[q][el];
+            __syncthreads();
+        }
+        if (kl == 0 && e < total) {
+            const int cc = (int)(e % (2 * Co)); const size_t r = e / (2 * Co); const int ci = (int)(r % Ci); const int i2 = (int)(r / Ci);
+            const int j2 = cc / Co, c = cc - j2 * Co;
+            out[((size_t)ci * Co + c) * 4 + i2 * 2 + j2] = s;
+        }
     }
 }
 
@@ -638,8 +655,14 @@ extern "C" int unet_pack_weights(int dtype, int mode, const float* src, void* ds
 
 extern "C" int unet_convT_wgrad_reduce(const float* slab, float* dw, int nsplit, int Ci, int Co, void* stream) {
     const size_t total = (size_t)4 * Ci * Co;
-    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(convT_wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, dw, nsplit, Ci, Co);
+    UNET_CHECK(slab != nullptr && dw != nullptr && nsplit > 0 && Ci > 0 && Co > 0, "convT_wgrad_reduce: bad argument");
+    if (total < 262144 && nsplit >= 16) {
+        const int grid = (int)((total + 31) / 32);
+        hipLaunchKernelGGL(convT_wgrad_reduce_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, dw, nsplit, Ci, Co);
+    } else {
+        int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(convT_wgrad_reduce_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, slab, dw, nsplit, Ci, Co);
+    }
     UNET_LAUNCH_CHECK();
     return 0;
 }
