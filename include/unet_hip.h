@@ -145,6 +145,10 @@ int unet_relu_bwd(int dtype, const void* dy, int ldd, int doff, const void* y, i
                   void* dz, int ldo, int ooff, long long M, int C, void* stream);
 int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, long long M, int C, float* out, int accumulate,
                      double* acc_ws, void* stream);
+/* out[c] = sum over r of rows[r*ld + off + c*stride]: column sums of the fp32 partial rows a conv epilogue wrote.  The bias
+ * gradient of nn.ConvTranspose2d (models/unet.py:35) is taken this way from the statistics rows of the split dgrad that
+ * produced its output gradient.  No workspace, no atomics, fixed summation order. */
+int unet_rows_colsum(const float* rows, int nrows, int ld, int off, int C, int stride, float* out, void* stream);
 
 /* ---- MaxPool2d(2,2) with argmax -- models/unet.py:26,47 --------------------------------------
  * code[n,ho,wo,c] = 2*dh+dw of the winner (ATen tie rule: first in row-major order, NaN wins);

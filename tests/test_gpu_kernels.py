@@ -437,3 +437,20 @@ def test_argmax_ensemble_metrics_vs_reference_golden(dev):
     got0 = calculate_segmentation_metrics(z, z, 2)
     for k, v in j["empty_metrics"].items():
         assert abs(got0[k] - v) < 1e-6, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nrows", [1, 63, 64, 300, 16384])
+def test_rows_colsum_matches_torch(dev, nrows):
+    """Column sums of fp32 partial rows (the ConvTranspose2d bias gradient is read off the split dgrad's statistics rows)."""
+    from unet_amd import ops
+    g = torch.Generator(device=dev).manual_seed(nrows)
+    ctot, f = 24, 8
+    rows = torch.randn((nrows, ctot, 2), generator=g, device=dev)
+    got = ops.rows_colsum(rows, 2 * f, ctot - f, 2)
+    ref = rows[:, f:, 0].double().sum(0)
+    torch.testing.assert_close(got.double(), ref, rtol=1e-6, atol=1e-4)
+    again = ops.rows_colsum(rows, 2 * f, ctot - f, 2)
+    assert torch.equal(got, again)                       # fixed summation order
+    with pytest.raises(ops.UNetHipError):
+        ops.rows_colsum(rows, 2 * f, ctot, 2)            # columns past the end of the row

@@ -575,6 +575,43 @@ extern "C" int unet_bn_finalize(const float* stat_rows, int nrows, int C, long l
     return 0;
 }
 
+// out[c] = sum_r rows[r*ld + off + c*stride]: column sums of fp32 partial rows (the ConvTranspose2d bias gradient from the
+// statistics rows of the split dgrad, models/unet.py:35 autograd).  4 columns x 64 row lanes per workgroup, four loads in
+// flight, partials added in lane order: no atomics, no workspace, deterministic.
+__global__ __launch_bounds__(256) void rows_colsum_kernel(const float* __restrict__ rows, int nrows, int ld, int off, int C, int stride,
+                                                          float* __restrict__ out) {
+    const int ch = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + ch;
+    double s = 0.0;
+    if (c < C) {
+        const float* col = rows + off + (size_t)c * stride;
+        int r = pl;
+        for (; r + 192 < nrows; r += 256) {
+            const float v0 = col[(size_t)r * ld], v1 = col[(size_t)(r + 64) * ld];
+            const float v2 = col[(size_t)(r + 128) * ld], v3 = col[(size_t)(r + 192) * ld];
+            s += (double)v0; s += (double)v1; s += (double)v2; s += (double)v3;
+        }
+        for (; r < nrows; r += 64) s += (double)col[(size_t)r * ld];
+    }
+    __shared__ double red[64][4];
+    red[pl][ch] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        double a = 0.0;
+        for (int p = 0; p < 64; ++p) a += red[p][ch];
+        out[c] = (float)a;
+    }
+}
+
+extern "C" int unet_rows_colsum(const float* rows, int nrows, int ld, int off, int C, int stride, float* out, void* stream) {
+    UNET_CHECK(rows != nullptr && out != nullptr, "rows_colsum: null argument");
+    UNET_CHECK(nrows > 0 && C > 0 && stride > 0 && off >= 0 && ld > 0 && off + (long long)(C - 1) * stride < ld,
+               "rows_colsum: columns outside the row (nrows=%d ld=%d off=%d C=%d stride=%d)", nrows, ld, off, C, stride);
+    hipLaunchKernelGGL(rows_colsum_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, rows, nrows, ld, off, C, stride, out);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
                                    const float* running_var, float eps, float* scale, float* shift, void* stream) {
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,

@@ -328,8 +328,7 @@ class UNetEngine:
             if len(res) > 2:        # [tiles][2f][sum, sum of squares] from the dgrad epilogue
                 rows = res[2]
                 ctot = rows.shape[1]
-                sums = ops.channel_sum(ops.Act(rows.view(1, 1, rows.shape[0], ctot * 2), 2 * f, 2 * (ctot - f)), ws)
-                grads[tname + ".bias"] = sums.view(-1, 2)[:, 0].contiguous()
+                grads[tname + ".bias"] = ops.rows_colsum(rows, 2 * f, ctot - f, 2)      # the sums of the upsampled half
             else:
                 grads[tname + ".bias"] = ops.channel_sum(dup, ws)
             grads[tname + ".weight"] = self.wgrad_async(dev, lambda w_: ops.convT_wgrad(xin, dup, w_), [xin.buf, dup.buf])

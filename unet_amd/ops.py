@@ -476,6 +476,17 @@ def channel_sum(x: Act, ws: Workspace, out: Optional[torch.Tensor] = None, accum
     return out
 
 
+def rows_colsum(rows: torch.Tensor, off: int, C: int, stride: int) -> torch.Tensor:
+    """out[c] = sum_r rows2d[r, off + c*stride] for fp32 partial rows [nrows, ...] (deterministic, no workspace)."""
+    _need_cuda(rows)
+    if rows.dtype != torch.float32 or not rows.is_contiguous() or rows.dim() < 2:
+        raise UNetHipError("rows_colsum: rows must be a contiguous fp32 tensor [nrows, ...]")
+    nrows, ld = rows.shape[0], rows.numel() // rows.shape[0]
+    out = torch.empty((C,), dtype=torch.float32, device=rows.device)
+    check(lib().unet_rows_colsum(_p(rows), nrows, ld, off, C, stride, _p(out), _stream()), "rows_colsum")
+    return out
+
+
 def maxpool_fwd(x: Act):
     """-> (pooled dense Act, uint8 code tensor [N,H/2,W/2,C])."""
     x.check()
