@@ -117,8 +117,11 @@ int unet_bn_finalize(const float* stat_rows, int nrows, int C, long long count,
                      float momentum, float eps,
                      float* scale, float* shift, float* mean, float* invstd,
                      double* acc_ws, void* stream);
+/* eval mode (running statistics): scale = gamma/sqrt(rv+eps), shift = beta - rm*scale; mean / invstd (nullable) receive
+ * rm and 1/sqrt(rv+eps) for a backward pass through the frozen statistics (relu bit 1 of unet_bn_relu_bwd). */
 int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
-                        const float* running_var, float eps, float* scale, float* shift, void* stream);
+                        const float* running_var, float eps, float* scale, float* shift,
+                        float* mean, float* invstd, void* stream);
 /* y = act(z*scale + shift) */
 int unet_affine_act(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
                     const float* scale, const float* shift, long long M, int C, void* stream);
@@ -127,7 +130,9 @@ int unet_affine_act(int dtype, int relu, const void* z, int ldz, int zoff, void*
 int unet_affine_act_pool(int dtype, int relu, const void* z, int ldz, int zoff, void* y, int ldy, int yoff,
                          const float* scale, const float* shift, void* pooled, uint8_t* code,
                          int N, int H, int W, int C, void* stream);
-/* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z */
+/* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z.
+ * relu: bit 0 = ReLU after the norm; bit 1 = frozen statistics (model.eval() with gradients enabled: mean / invstd are
+ * the running statistics and carry no gradient): dz = scale*dy', dgamma = sum dy'*(z-mean)*invstd, dbeta = sum dy'. */
 int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
                      void* dz, int ldo, int ooff,
                      const float* scale, const float* shift, const float* mean, const float* invstd,

@@ -80,14 +80,28 @@ def batchnorm(x, st: State, prefix: str, train: bool, momentum: float, new_buffe
     return y
 
 
-def double_conv(x, st: State, p: str, train: bool, nb: Optional[State], emu: bool = False, first: bool = False):
+def _relu(x, key: str, decisions: Optional[dict], taps: Optional[dict]):
+    """ReLU.  `decisions[key]` (a bool mask) pins WHICH side of the kink every element is on: ReLU and max-pool make
+    the network piecewise linear, and two correct fp32 evaluations whose pre-activations differ by rounding can put an
+    element with |pre-activation| ~ 1e-6 on different sides; its whole upstream gradient then moves by ~1e-2 (the BN
+    batch sums that follow lose one term of a heavily cancelling sum).  A parity test that compares gradients to 1e-4
+    therefore evaluates the oracle on the SAME linear piece as the path under test and checks separately that every
+    pinned decision was a genuine near-tie (tests/test_gpu_realwidth.py)."""
+    y = F.relu(x) if decisions is None else x * decisions[key].to(x.dtype)
+    if taps is not None:
+        taps["relu/" + key] = y
+    return y
+
+
+def double_conv(x, st: State, p: str, train: bool, nb: Optional[State], emu: bool = False, first: bool = False,
+                decisions: Optional[dict] = None, taps: Optional[dict] = None):
     """unet.py:9-16: conv3x3(pad 1, bias) -> BN -> ReLU, twice; params at indices 0,1,3,4.
     emu=True rounds to bf16 wherever the HIP bf16 path stores a tensor (conv output, BN+ReLU output,
     packed weights; the Cin<=4 first conv keeps fp32 weights) so the bf16 kernels can be checked tightly."""
     x = F.conv2d(x, _rw(st[p + ".double_conv.0.weight"], emu and not first), st[p + ".double_conv.0.bias"], padding=1)
-    x = _ra(F.relu(batchnorm(_ra(x, emu), st, p + ".double_conv.1", train, BN_MOMENTUM, nb)), emu)
+    x = _ra(_relu(batchnorm(_ra(x, emu), st, p + ".double_conv.1", train, BN_MOMENTUM, nb), p + ".a", decisions, taps), emu)
     x = F.conv2d(x, _rw(st[p + ".double_conv.3.weight"], emu), st[p + ".double_conv.3.bias"], padding=1)
-    x = _ra(F.relu(batchnorm(_ra(x, emu), st, p + ".double_conv.4", train, BN_MOMENTUM, nb)), emu)
+    x = _ra(_relu(batchnorm(_ra(x, emu), st, p + ".double_conv.4", train, BN_MOMENTUM, nb), p + ".b", decisions, taps), emu)
     return x
 
 
@@ -99,7 +113,8 @@ def _levels(st: State) -> int:
     return n
 
 
-def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: bool = False):
+def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: bool = False,
+          decisions: Optional[dict] = None):
     """Encoder/decoder wiring shared by UNet.forward (unet.py:41-62) and
     ReparamUNet.forward (reparm_unet.py:194-215): skip FIRST in the concat."""
     skips = []
@@ -108,7 +123,12 @@ def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: 
         skips.append(x)
         if taps is not None:
             taps[f"skip{i}"] = x
-        x = F.max_pool2d(x, 2, 2)                                           # unet.py:26,47
+            taps[f"pool{i}"] = F.max_pool2d(x.detach(), 2, 2, return_indices=True)[1]
+        if decisions is None:
+            x = F.max_pool2d(x, 2, 2)                                       # unet.py:26,47
+        else:                                                               # pinned argmax (see _relu)
+            idx = decisions[f"pool{i}"]
+            x = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
     x = block(x, "bottleneck")                                              # unet.py:49
     skips = skips[::-1]
     for j in range(n_levels):
@@ -122,10 +142,13 @@ def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: 
 
 
 def unet_forward(x, st: State, train: bool = True, new_buffers: Optional[State] = None, taps=None,
-                 emulate_bf16: bool = False):
+                 emulate_bf16: bool = False, decisions: Optional[dict] = None):
+    """decisions: {"<block>.a" / "<block>.b": bool ReLU masks (NCHW), "pool<i>": int64 max-pool indices} pins the linear
+    piece the network is evaluated on (see _relu); taps receives the oracle's own post-ReLU tensors and pool indices."""
     n = _levels(st)
-    return _wire(x, st, lambda t, p: double_conv(t, st, p, train, new_buffers, emulate_bf16, first=(p == "downs.0" and t is x)),
-                 n, taps, emulate_bf16)
+    return _wire(x, st, lambda t, p: double_conv(t, st, p, train, new_buffers, emulate_bf16, first=(p == "downs.0" and t is x),
+                                                 decisions=decisions, taps=taps),
+                 n, taps, emulate_bf16, decisions)
 
 
 # ---------------------------------------------------------------- RepUNet --------------

@@ -277,3 +277,55 @@ def test_wgrad_side_stream_gives_identical_gradients(dev):
             assert torch.equal(a[k], b[k]), k
         else:
             torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-6)
+
+
+def _randomize_running_stats(st, seed=3):
+    gen = torch.Generator().manual_seed(seed)
+    for k in st:
+        if k.endswith("running_mean"):
+            st[k] = torch.randn(st[k].shape, generator=gen) * 0.1
+        if k.endswith("running_var"):
+            st[k] = torch.rand(st[k].shape, generator=gen) + 0.5
+    return st
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_eval_mode_backward_matches_oracle(dev, dtype):
+    """loss.backward() under model.eval() (frozen-BN fine-tuning, saliency): BatchNorm uses the running statistics, which
+    carry no gradient -- dz = scale*dy', dgamma = sum dy'*(z-rm)*invstd, dbeta = sum dy'.  Against torch autograd through
+    the oracle's eval-mode forward (F.batch_norm(training=False))."""
+    from oracle import loss_ref, unet_ref
+    from unet_amd.losses import get_loss
+    m, g = build("unet_f8x16x32x64", dev)
+    st = _randomize_running_stats({k: v.clone() for k, v in split(g, "init/").items()})
+    m.load_state_dict(st)
+    m.eval()
+    m.compute_dtype = dtype
+    names = [k for k in st if "running_" not in k and "num_batches" not in k]
+    for k in names:
+        st[k].requires_grad_(True)
+    ref = unet_ref.unet_forward(g["x"], st, train=False)
+    loss_ref.ce_dice(ref, g["y"], 1.0, 1.0, 255).backward()
+    out = m(g["x"].to(dev))
+    get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)(out, g["y"].to(dev)).backward()
+    for k, b in m.named_buffers():
+        assert torch.equal(b.cpu(), st[k].detach()), k                     # eval must not touch the buffers
+    if dtype == "fp32":
+        assert relmax(out.detach().cpu(), ref.detach()) < 1e-4
+        for k, p in m.named_parameters():
+            assert p.grad is not None, k
+            assert relmax(p.grad.cpu(), st[k].grad) < 1e-4, (k, relmax(p.grad.cpu(), st[k].grad))
+    else:
+        assert rell2(out.detach().float().cpu(), ref.detach()) < 2e-2
+        for k, p in m.named_parameters():
+            assert rell2(p.grad.cpu(), st[k].grad) < 6e-2, (k, rell2(p.grad.cpu(), st[k].grad))
+
+
+def test_input_requiring_grad_is_refused(dev):
+    from unet_amd import UNetHipError
+    m, g = build("unet_f8x16", dev)
+    x = g["x"].to(dev).requires_grad_(True)
+    with pytest.raises(UNetHipError):
+        m(x)
+    with torch.no_grad():
+        m(x)                                   # fine when no graph is being built

@@ -1,0 +1,340 @@
+"""Oracle parity at the BENCHMARK's channel widths (BASELINE configs[1]: features [64,128,256,512], bottleneck 1024).
+
+tests/test_gpu_kernels.py checks every kernel on small channel counts and tests/test_gpu_fullsize.py checks the full
+32x1x512x512 shapes through size-independent properties; this file closes the gap between them: the exact kernel
+instantiations bench.py times (conv3x3_v2<2,false>, the deferred-statistics 64-channel variant <1,false,true>,
+bn_stats_finalize, rows_colsum bias gradient, split dgrad, conv_wgrad2, convT2 at 512 / 1024 channels, fused pool
+passes) compared with torch-CPU fp32 (F.conv2d / F.conv_transpose2d; accumulation over K = 9*1024 = 9216) and, for
+the whole engine, with the pinned oracle (oracle/unet_ref.py, oracle/loss_ref.py) computed live on the same inputs.
+
+Spatial sizes are multiples of the 16x32 output tile so the specialised (GEN=false) paths run.
+
+Tolerances: fp32 mode <= 1e-4 relative (max-abs error / max-abs reference per tensor), as north_star states;
+bf16 per kernel: both sides see bf16-rounded inputs, fp32 accumulation, only the output rounding differs (see
+tests/test_gpu_kernels.py::close); bf16 whole model: stated in test_engine_real_widths_bf16 below.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_kernels import close, from_act, q, rnd, to_act
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def relmax(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rell2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+# N, H, W, Cin, Cout: the (Cin, Cout) pairs of the benchmark model's 3x3 convs (SURVEY 8(d) per-layer table)
+REAL_CONV = [
+    (2, 32, 64, 64, 64),        # down0.b / up3.b  (64-channel tiles, deferred BN statistics)
+    (2, 32, 64, 128, 64),       # up3.a
+    (1, 32, 32, 64, 128),       # down1.a
+    (1, 32, 32, 128, 128),      # down1.b / up2.b
+    (1, 16, 64, 256, 128),      # up2.a
+    (1, 16, 32, 128, 256),      # down2.a
+    (1, 16, 32, 256, 256),      # down2.b / up1.b
+    (1, 16, 32, 512, 256),      # up1.a
+    (1, 16, 32, 256, 512),      # down3.a
+    (1, 16, 32, 512, 512),      # down3.b / up0.b
+    (1, 16, 32, 1024, 512),     # up0.a
+    (1, 16, 32, 512, 1024),     # bott.a
+    (1, 16, 32, 1024, 1024),    # bott.b
+]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", REAL_CONV)
+def test_conv3x3_real_widths(dev, dt, shape):
+    from unet_amd import ops
+    N, H, W, Cin, Cout = shape
+    x = q(rnd((N, Cin, H, W), 101), dt)
+    w = q(rnd((Cout, Cin, 3, 3), 102, (Cin * 9) ** -0.5), dt)
+    b = rnd((Cout,), 103)
+    x.requires_grad_(True); w.requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=1)
+    dyv = q(rnd(tuple(ref.shape), 104), dt)
+    ref.backward(dyv)
+
+    xa = to_act(x.detach(), dt, dev)
+    ya = ops.dense(N, H, W, Cout, dt, dev)
+    rows = ops.conv_fwd(xa, ops.pack_weights(w.detach().to(dev), 0, dt), b.to(dev), ya, 3, 3, Cin, Cout, stats=True)
+    close(from_act(ya), ref.detach(), dt, "conv fwd")
+    s = rows.double().sum(0).cpu()
+    r = ref.detach().double()
+    close(s[:, 0].float(), r.sum((0, 2, 3)).float(), dt, "stats sum", f32_out=True)
+    close(s[:, 1].float(), (r * r).sum((0, 2, 3)).float(), dt, "stats sumsq", f32_out=True)
+
+    dza = to_act(dyv, dt, dev)
+    dxa = ops.dense(N, H, W, Cin, dt, dev)
+    wd = ops.pack_weights(w.detach().to(dev), 1, dt)
+    ops.conv_fwd(dza, wd, None, dxa, 3, 3, Cout, Cin)
+    close(from_act(dxa), x.grad, dt, "conv dgrad")
+
+    # the decoder's first conv hands the two halves of the concat gradient to two buffers and takes the ConvTranspose2d
+    # bias gradient from the epilogue's statistics rows (engine.block_bwd, split_f)
+    if Cin == 2 * Cout:
+        f = Cout
+        d1, d2 = ops.dense(N, H, W, f, dt, dev), ops.dense(N, H, W, f, dt, dev)
+        rows2 = ops.conv_fwd(dza, wd, None, d1, 3, 3, Cout, Cin, y2=d2, csplit=f, stats=True)
+        close(from_act(d1), x.grad[:, :f], dt, "split dgrad skip half")
+        close(from_act(d2), x.grad[:, f:], dt, "split dgrad up half")
+        dbias = ops.rows_colsum(rows2, 2 * f, Cin - f, 2)
+        close(dbias.cpu(), x.grad[:, f:].double().sum((0, 2, 3)).float(), dt, "convT bias grad from rows", f32_out=True)
+
+    dw, _, _ = ops.conv_wgrad(dza, xa, 3, 3, ops.Workspace(dev))
+    close(dw.view(Cout, Cin, 3, 3).cpu(), w.grad, dt, "conv wgrad", f32_out=True)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 1024, 512), (1, 16, 32, 512, 256), (1, 16, 32, 256, 128), (2, 16, 32, 128, 64)])
+def test_conv_transpose_real_widths(dev, dt, shape):
+    from unet_amd import ops
+    N, h, w_, Ci, Co = shape
+    x = q(rnd((N, Ci, h, w_), 107), dt)
+    wt = q(rnd((Ci, Co, 2, 2), 108, Ci ** -0.5), dt)
+    b = rnd((Co,), 109)
+    x.requires_grad_(True); wt.requires_grad_(True)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    dyv = q(rnd(tuple(ref.shape), 110), dt)
+    ref.backward(dyv)
+    xa = to_act(x.detach(), dt, dev)
+    cat = torch.zeros((N, 2 * h, 2 * w_, 2 * Co), dtype=ops.torch_dtype(dt), device=dev)
+    ops.conv_fwd(xa, ops.pack_weights(wt.detach().to(dev), 2, dt), b.to(dev), ops.Act(cat, Co, Co), 1, 1, Ci, 4 * Co, epi=1)
+    close(from_act(ops.Act(cat, Co, Co)), ref.detach(), dt, "convT fwd")
+    assert float(cat[..., :Co].float().abs().max()) == 0.0
+    dup = to_act(dyv, dt, dev)
+    dx = ops.dense(N, h, w_, Ci, dt, dev)
+    ops.convT_dgrad(dup, ops.pack_weights(wt.detach().to(dev), 3, dt), Ci, dx)
+    close(from_act(dx), x.grad, dt, "convT dgrad")
+    dw = ops.convT_wgrad(xa, dup, ops.Workspace(dev))
+    close(dw.cpu(), wt.grad, dt, "convT wgrad", f32_out=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole engine at the benchmark's widths against the pinned oracle, computed live
+#
+# ReLU and max-pool make the network piecewise linear.  Two correct fp32 evaluations differ by summation-order
+# rounding (~1e-6 after a K = 1152 ... 9216 reduction), so out of the ~3.5 M ReLU decisions of this model one or two
+# elements with |pre-activation| ~ 1e-6 land on different sides of zero (measured: tools/diag_masks.py, 2 of 3.5 M).
+# Each such flip drops one term from a BatchNorm backward batch sum that cancels to ~1 % of its terms, and every
+# gradient upstream moves by ~1e-2 -- in the reference on another machine just as here.  The comparison is therefore
+# made on the SAME linear piece: the oracle is evaluated with the HIP path's ReLU masks and pool winners
+# (oracle/unet_ref.py `decisions`), and the test separately requires that every decision on which the free-running
+# oracle disagrees is a genuine near-tie and that there are almost none of them.
+
+FEATURES = [64, 128, 256, 512]
+
+
+def _noise_bias(k):
+    return k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias")
+
+
+def _nchw(act):
+    return act.buf[..., act.off:act.off + act.C].float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def _hip_decisions(engine):
+    """Post-ReLU tensors and pool winners of the engine's last training forward (engine.keep_saved)."""
+    from unet_amd import ops
+    sv = engine.last_saved
+    L = len(engine.features)
+    post, pool = {}, {}
+    for p, (r1, r2) in sv.blocks.items():
+        post[p + ".a"] = _nchw(r2.xin)                      # the first conv's BN+ReLU output is the second conv's input
+    for i, f in enumerate(engine.features):
+        post[f"downs.{i}.b"] = sv.cats[i][..., :f].float().cpu().permute(0, 3, 1, 2).contiguous()
+        pool[f"pool{i}"] = ops.pool_indices_int64(sv.codes[i], sv.cats[i].shape[2]).cpu()
+    post["bottleneck.b"] = _nchw(sv.up_in[0])
+    for j in range(L):
+        post[f"ups.{2 * j + 1}.b"] = _nchw(sv.up_in[j + 1]) if j + 1 < L else _nchw(sv.last)
+    return post, pool
+
+
+def _oracle(x, y, state, emulate_bf16=False, decisions=None, taps=None):
+    from oracle import loss_ref, unet_ref
+    st = {k: v.clone() for k, v in state.items()}
+    names = [k for k in st if "running_" not in k and "num_batches" not in k]
+    for k in names:
+        st[k].requires_grad_(True)
+    nb = {}
+    logits = unet_ref.unet_forward(x, st, True, nb, emulate_bf16=emulate_bf16, decisions=decisions, taps=taps)
+    loss = loss_ref.ce_dice(logits, y, 1.0, 1.0, 255)
+    loss.backward()
+    return logits.detach(), float(loss.detach()), {k: st[k].grad for k in names}, nb
+
+
+@pytest.fixture(scope="module")
+def real_case():
+    """UNet[64,128,256,512], 2x1x64x64: the 3x3 layers cover whole 16x32 tiles down to 16x32 at level 2 (the deeper
+    levels, 8x8 and 4x4, run the general path exactly as they would for any input that small)."""
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(42)
+    m = REGISTRY["unet"](in_channels=1, n_classes=2, features=FEATURES)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(2, 1, 64, 64, generator=g)
+    y = (torch.rand(2, 64, 64, generator=g) > 0.95).long()
+    taps = {}
+    free = _oracle(x, y, state, taps=taps)
+    return m, state, x, y, free, taps
+
+
+def _run_hip(m, state, x, y, dev, mode):
+    from unet_amd.losses import get_loss
+    m.load_state_dict(state)
+    m = m.to(dev).train()
+    m.compute_dtype = mode
+    m._engine.keep_saved = True
+    m.zero_grad(set_to_none=True)
+    logits = m(x.to(dev))
+    loss = get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)(logits, y.to(dev))
+    loss.backward()
+    post, pool = _hip_decisions(m._engine)
+    m._engine.keep_saved = False
+    m._engine.last_saved = None
+    grads = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    bufs = {k: b.detach().cpu().clone() for k, b in m.named_buffers()}
+    return logits.detach().float().cpu(), float(loss.detach()), grads, bufs, post, pool
+
+
+def _decision_report(post, pool, taps, tie_tol):
+    """(#ReLU decisions, #flips, #pool flips); asserts every disagreement with the free-running oracle is a near-tie."""
+    total = flips = pflips = 0
+    for key, yh in post.items():
+        yr = taps["relu/" + key].detach()
+        mism = (yh > 0) != (yr > 0)
+        total += mism.numel()
+        flips += int(mism.sum())
+        if mism.any():                  # one side is exactly 0, the other must be within rounding of it
+            assert float(torch.maximum(yh.abs(), yr.abs())[mism].max()) <= tie_tol, key
+    for key, idx in pool.items():
+        ri = taps[key]
+        mism = idx != ri
+        pflips += int(mism.sum())
+        if mism.any():                  # both winners must hold (nearly) the same value
+            i = int(key[4:])
+            src = taps[f"skip{i}"].detach().flatten(2)
+            a, b = src.gather(2, idx.flatten(2)), src.gather(2, ri.flatten(2))
+            assert float((a - b).abs()[mism.flatten(2)].max()) <= tie_tol, key
+    return total, flips, pflips
+
+
+def test_engine_real_widths_fp32(dev, real_case):
+    m, state, x, y, free, taps = real_case
+    logits, loss, grads, bufs, post, pool = _run_hip(m, state, x, y, dev, "fp32")
+    total, flips, pflips = _decision_report(post, pool, taps, tie_tol=2e-5)
+    assert flips <= 2e-5 * total and pflips <= 8, (flips, pflips, total)
+    # forward: no pinning needed (a flipped element is ~1e-6 either way)
+    ref_logits, ref_loss = free[0], free[1]
+    assert relmax(logits, ref_logits) < 1e-4
+    assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss)
+    assert torch.equal(logits.argmax(1), ref_logits.argmax(1))
+    for k, b in bufs.items():
+        r = free[3][k]
+        if r.dtype == torch.int64:
+            assert torch.equal(b, r), k
+        else:
+            assert relmax(b, r) < 1e-5, k
+    # backward: on the linear piece the HIP path evaluated
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    pin_logits, _, ref_grads, _ = _oracle(x, y, state, decisions=dec)
+    assert relmax(pin_logits, ref_logits) < 1e-5          # pinning near-ties does not move the forward
+    gmax = max(float(v.abs().max()) for v in ref_grads.values())
+    worst = ("", 0.0)
+    for k, gk in grads.items():
+        r = ref_grads[k]
+        if _noise_bias(k):
+            assert float((gk - r).abs().max()) < 1e-5 * gmax, k
+        else:
+            e = relmax(gk, r)
+            if e > worst[1]:
+                worst = (k, e)
+            assert e < 1e-4, (k, e)
+    print(f"fp32 real widths: {flips} ReLU flips of {total}, {pflips} pool flips; logits relmax {relmax(logits, ref_logits):.2e}, "
+          f"worst grad relmax {worst[1]:.2e} ({worst[0]})")
+    m.cpu()
+
+
+# Stated bf16 tolerance for the whole model at the benchmark's widths (measured values: DESIGN.md 3.2):
+BF16_LOGITS_RELL2 = 2e-2
+BF16_LOSS_REL = 1e-2
+BF16_ARGMAX_AGREE = 0.995
+BF16_GRAD_RELL2_PINNED = 8e-2     # per parameter tensor, fp32 oracle on the HIP path's linear piece (measured worst: 5.9e-2)
+
+
+def test_engine_real_widths_bf16(dev, real_case):
+    m, state, x, y, free, taps = real_case
+    logits, loss, grads, _, post, pool = _run_hip(m, state, x, y, dev, "bf16")
+    ref_logits, ref_loss, free_grads = free[0], free[1], free[2]
+    e_log = rell2(logits, ref_logits)
+    e_loss = abs(loss - ref_loss) / abs(ref_loss)
+    agree = float((logits.argmax(1) == ref_logits.argmax(1)).float().mean())
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    flips = sum(int(((v > 0) != (taps["relu/" + k].detach() > 0)).sum()) for k, v in post.items())
+    total = sum(v.numel() for v in post.values())
+    _, _, pin_grads, _ = _oracle(x, y, state, decisions=dec)
+    worst, worst_free = ("", 0.0), ("", 0.0)
+    for k, gk in grads.items():
+        if _noise_bias(k):
+            continue
+        e = rell2(gk, pin_grads[k])
+        if e > worst[1]:
+            worst = (k, e)
+        ef = rell2(gk, free_grads[k])
+        if ef > worst_free[1]:
+            worst_free = (k, ef)
+    print(f"bf16 real widths: logits rel-L2 {e_log:.3e}, loss rel {e_loss:.3e}, argmax agreement {agree:.5f}; "
+          f"{flips} of {total} ReLU decisions differ from the fp32 oracle; worst grad rel-L2 on the same linear piece "
+          f"{worst[1]:.3e} ({worst[0]}), against the free-running fp32 oracle {worst_free[1]:.3e} ({worst_free[0]})")
+    assert e_log <= BF16_LOGITS_RELL2 and e_loss <= BF16_LOSS_REL and agree >= BF16_ARGMAX_AGREE
+    assert worst[1] <= BF16_GRAD_RELL2_PINNED, worst
+    m.cpu()
+
+
+def test_bf16_vs_fp32_loss_trajectory(dev):
+    """30 full step_batch calls (fused clip + AdamW) from the same init, fp32 kernels against bf16 kernels: the two
+    loss curves must fall together.  Stated bound: |loss_bf16 - loss_fp32| <= 3e-2 * loss_fp32 at every step, and
+    both end below 75 % of where they started."""
+    import logging
+    import types
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    from unet_amd.utils.builders import get_optim
+    from unet_amd.utils.train_step import step_batch
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(4, 1, 64, 64, generator=g).to(dev)
+    # a learnable target: the mask is a function of the image
+    y = (F.avg_pool2d(x, 5, 1, 2)[:, 0] > 0.55).long()
+
+    def run(amp):
+        torch.manual_seed(42)
+        m = REGISTRY["unet"](in_channels=1, n_classes=2, features=[16, 32, 64, 128]).to(dev).train()
+        opt = get_optim("adamw", m.parameters(), lr=1e-3, weight_decay=1e-4)
+        tr = types.SimpleNamespace(optimizer=opt, amp=amp, model=m, grad_clip=1.0, cbs=[], current_epoch=1,
+                                   logger=logging.getLogger("t"), loss_fn=get_loss("ce_dice", ignore_index=255))
+        out = []
+        for i in range(30):
+            _, _, info = step_batch(tr, x, y, torch.amp.GradScaler(enabled=False), i)
+            out.append(info["main_loss"])
+        return out
+
+    a, b = run(False), run(True)
+    dev_max = max(abs(p - r) / r for p, r in zip(b, a))
+    print(f"loss trajectory fp32 {a[0]:.4f} -> {a[-1]:.4f}, bf16 {b[0]:.4f} -> {b[-1]:.4f}, max relative gap {dev_max:.3e}")
+    assert a[-1] < 0.75 * a[0] and b[-1] < 0.75 * b[0]
+    assert dev_max <= 3e-2

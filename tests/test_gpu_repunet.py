@@ -133,3 +133,33 @@ def test_repunet_batchnorm_variant_train_vs_oracle(dev):
             assert torch.equal(b.cpu(), nb[k]), k
         else:
             assert relmax(b.cpu(), nb[k]) < 1e-5, k
+
+
+def test_repunet_batchnorm_variant_eval_backward_vs_oracle(dev):
+    """Backward through an eval-mode (running statistics) BatchNorm RepUNet: the frozen-statistics BN backward."""
+    from oracle import loss_ref, unet_ref
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(5)
+    m = REGISTRY["reparam_unet"](in_channels=1, n_classes=2, features=[8, 16], kernel_sizes=[3], norm="batch")
+    st = {k: v.clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    for k in st:
+        if k.endswith("running_mean"):
+            st[k] = torch.randn(st[k].shape, generator=gen) * 0.1
+        if k.endswith("running_var"):
+            st[k] = torch.rand(st[k].shape, generator=gen) + 0.5
+    m.load_state_dict(st)
+    x = torch.rand(2, 1, 32, 32, generator=gen)
+    y = (torch.rand(2, 32, 32, generator=gen) > 0.9).long()
+    names = [k for k in st if "running_" not in k and "num_batches" not in k]
+    for k in names:
+        st[k].requires_grad_(True)
+    ref = unet_ref.repunet_forward(x, st, [3], norm="batch", train=False)
+    loss_ref.ce_dice(ref, y, 1.0, 1.0, 255).backward()
+    m = m.to(dev).eval()
+    out = m(x.to(dev))
+    get_loss("ce_dice", ignore_index=255)(out, y.to(dev)).backward()
+    assert relmax(out.detach().cpu(), ref.detach()) < 1e-4
+    for k, p in m.named_parameters():
+        assert relmax(p.grad.cpu(), st[k].grad) < 3e-4, (k, relmax(p.grad.cpu(), st[k].grad))

@@ -132,13 +132,16 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 // eval mode: coefficients from the running statistics
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps,
-                                      float* __restrict__ scale, float* __restrict__ shift) {
+                                      float* __restrict__ scale, float* __restrict__ shift,
+                                      float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float invstd = 1.0f / sqrtf(rv[c] + eps);
     const float sc = gamma[c] * invstd;
     scale[c] = sc;
     shift[c] = beta[c] - rm[c] * sc;
+    if (mean_out != nullptr) mean_out[c] = rm[c];          // saved for a backward through frozen statistics
+    if (invstd_out != nullptr) invstd_out[c] = invstd;
 }
 
 // y = relu(z*scale + shift)   (relu optional)
@@ -295,8 +298,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(PoolSrc ps, const T*
     block_reduce_to_acc<2 * EPV>(m, part, EPV, C, acc, 2);
 }
 
-// pass 1 finalize: dgamma = S2, dbeta = S1, c1 = S1/n, c2 = S2/n
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, double count, int C,
+// pass 1 finalize: dgamma = S2, dbeta = S1, c1 = S1/n, c2 = S2/n.  frozen (eval-mode BN: mean / invstd are the
+// running statistics, constants of the batch): the statistics carry no gradient, so c1 = c2 = 0 and pass 2 reduces to
+// dz = scale * dy'.
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, double count, int C, int frozen,
                                        float* __restrict__ dgamma, float* __restrict__ dbeta,
                                        float* __restrict__ c1, float* __restrict__ c2) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -304,8 +309,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, double co
     const double s1 = acc[c * 2], s2 = acc[c * 2 + 1];
     dgamma[c] = (float)s2;
     dbeta[c] = (float)s1;
-    c1[c] = (float)(s1 / count);
-    c2[c] = (float)(s2 / count);
+    c1[c] = frozen ? 0.f : (float)(s1 / count);
+    c2[c] = frozen ? 0.f : (float)(s2 / count);
 }
 
 // pass 2: dz = scale_g * (dy' - c1 - xhat*c2) with scale_g = gamma*invstd (= forward scale);
@@ -613,9 +618,11 @@ extern "C" int unet_rows_colsum(const float* rows, int nrows, int ld, int off, i
 }
 
 extern "C" int unet_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
-                                   const float* running_var, float eps, float* scale, float* shift, void* stream) {
+                                   const float* running_var, float eps, float* scale, float* shift,
+                                   float* mean /* nullable */, float* invstd /* nullable */, void* stream) {
+    UNET_CHECK(C > 0 && gamma && beta && running_mean && running_var && scale && shift, "bn_eval_coeffs: null argument");
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
-                       running_mean, running_var, eps, scale, shift);
+                       running_mean, running_var, eps, scale, shift, mean, invstd);
     UNET_LAUNCH_CHECK();
     return 0;
 }
@@ -660,6 +667,10 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
                             float* dgamma, float* dbeta, float* dbias, float* c1c2_ws, double* acc_ws,
                             long long M, int C, void* stream) {
     if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
+    UNET_CHECK(scale && shift && mean && invstd, "bn_relu_bwd: scale / shift / mean / invstd must not be NULL");
+    UNET_CHECK(dy && z && dz && dgamma && dbeta && c1c2_ws && acc_ws, "bn_relu_bwd: null argument");
+    const int frozen = (relu >> 1) & 1;
+    relu &= 1;
     UNET_CHECK(ldd % 8 == 0 && doff % 8 == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0,
                "bn_relu_bwd: strides/offsets must be multiples of 8");
     hipStream_t s = (hipStream_t)stream;
@@ -674,7 +685,7 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
     else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
     UNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)M, C, dgamma, dbeta, c1, c2);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)M, C, frozen, dgamma, dbeta, c1, c2);
     UNET_LAUNCH_CHECK();
     if (dtype == UNET_BF16) { if (relu) LAUNCH_A(__bf16, true); else LAUNCH_A(__bf16, false); }
     else { if (relu) LAUNCH_A(float, true); else LAUNCH_A(float, false); }

@@ -46,6 +46,8 @@ class UNetEngine:
         self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
         self.fused_pool_fwd = True   # UNet: max-pool fused into the BN+ReLU pass of the level's second conv
         self._pooled = None
+        self.keep_saved = False      # tests: leave the last forward's saved activations in self.last_saved
+        self.last_saved = None
         # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
         # filling between the big persistent kernels (a wgrad block starts on a CU the moment the dgrad conv's block
         # there retires; the two cannot share a CU, 134 + 151 KB of LDS).  OFF by default because queued-behind time
@@ -162,7 +164,7 @@ class UNetEngine:
             st = ops.bn_finalize(rows, z.M, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
                                  B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
         else:
-            st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS)
+            st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS, for_backward=save)
         y = yout if yout is not None else ops.dense(z.N, z.H, z.W, Cout, dt, dev)
         if pool:        # encoder level: the 2x2 max-pool rides on the BN+ReLU pass
             self._pooled = ops.affine_act_pool(z, y, st, relu=True)
@@ -249,6 +251,8 @@ class UNetEngine:
                                   P["final_conv.bias"].detach())
         if save:
             sv.last, sv.cats = cur, cats
+            if self.keep_saved:
+                self.last_saved = sv
         return logits, sv
 
     # ------------------------------------------------------------------ backward

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..rep_engine import RepUNetEngine
-from .unet import SlotCache, _UNetFn, resolve_dtype
+from .unet import SlotCache, _UNetFn, check_input_needs_no_grad, resolve_dtype
 
 
 def getConv2D(in_channels, out_channels, kernel_size=(3, 3), stride=1, padding=0, groups=1, bias=True):
@@ -150,6 +150,7 @@ class ReparamUNet(SlotCache, nn.Module):
         self._grad_hook = None
 
     def forward(self, x, current_epoch=None):
+        check_input_needs_no_grad(x)
         named = self.named_params_fast()
         params = [p for _, p in named]
         self._cur_names = [n for n, _ in named]

@@ -75,6 +75,14 @@ class SlotCache:
         return {n: d[k] for d, k, n in self._slots()[1] if d.get(k) is not None}
 
 
+def check_input_needs_no_grad(x):
+    """The engine's backward stops at the first conv (the reference's dataset tensors never require grad).  A caller that
+    asks for dL/dx (saliency, adversarial examples, a learnable stem in front) must not get a silent None."""
+    if torch.is_grad_enabled() and isinstance(x, torch.Tensor) and x.requires_grad:
+        raise ops.UNetHipError("unet_amd does not compute the gradient with respect to the input image "
+                               "(x.requires_grad is True): detach x, or run the model under torch.no_grad()")
+
+
 class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, dt, need_grad, x, *params):
@@ -134,6 +142,7 @@ class UNet(SlotCache, nn.Module):
         self._grad_hook = None
 
     def forward(self, x, current_epoch=None):
+        check_input_needs_no_grad(x)
         named = self.named_params_fast()
         params = [p for _, p in named]
         self._cur_names = [n for n, _ in named]

@@ -363,6 +363,7 @@ class BNState:
     shift: torch.Tensor
     mean: Optional[torch.Tensor] = None
     invstd: Optional[torch.Tensor] = None
+    frozen: bool = False        # eval-mode BatchNorm: mean / invstd are the running statistics (no gradient through them)
 
 
 def bn_finalize(rows: torch.Tensor, count: int, gamma, beta, running_mean, running_var, nbt, momentum, eps,
@@ -379,12 +380,27 @@ def bn_finalize(rows: torch.Tensor, count: int, gamma, beta, running_mean, runni
     return st
 
 
-def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps) -> BNState:
+def bn_eval_coeffs(gamma, beta, running_mean, running_var, eps, for_backward: bool = False) -> BNState:
+    """Eval-mode coefficients; for_backward also saves (running_mean, invstd) so bn_relu_bwd can run with frozen statistics."""
+    _need_cuda(gamma, beta, running_mean, running_var)
     C = gamma.numel()
-    buf = torch.empty((2, C), dtype=torch.float32, device=gamma.device)
+    for t in (gamma, beta, running_mean, running_var):
+        if t.numel() != C or t.dtype != torch.float32 or not t.is_contiguous():
+            raise UNetHipError("bn_eval_coeffs: per-channel tensors must be contiguous fp32 of equal length")
+    buf = torch.empty((4 if for_backward else 2, C), dtype=torch.float32, device=gamma.device)
     check(lib().unet_bn_eval_coeffs(C, _p(gamma), _p(beta), _p(running_mean), _p(running_var), float(eps), _p(buf[0]), _p(buf[1]),
+                                    _p(buf[2]) if for_backward else None, _p(buf[3]) if for_backward else None,
                                     _stream()), "bn_eval_coeffs")
+    if for_backward:
+        return BNState(buf[0], buf[1], buf[2], buf[3], frozen=True)
     return BNState(buf[0], buf[1])
+
+
+def _bn_bwd_flags(st: BNState, relu: bool) -> int:
+    if st.mean is None or st.invstd is None:
+        raise UNetHipError("bn_relu_bwd: this BatchNorm state was built without the statistics backward needs "
+                           "(bn_eval_coeffs(..., for_backward=True) for an eval-mode forward)")
+    return (1 if relu else 0) | (2 if st.frozen else 0)
 
 
 def affine_act(z: Act, y: Act, st: BNState, relu=True):
@@ -419,7 +435,7 @@ def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True,
     if 3 * C > ws.acc.numel() or 2 * C > ws.c1c2.numel():
         raise UNetHipError("bn_relu_bwd: workspace too small")
     g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
-    check(lib().unet_bn_relu_bwd(z.dt, 1 if relu else 0, _p(dy.buf), dy.ld, dy.off, _p(z.buf), z.ld, z.off,
+    check(lib().unet_bn_relu_bwd(z.dt, _bn_bwd_flags(st, relu), _p(dy.buf), dy.ld, dy.off, _p(z.buf), z.ld, z.off,
                                  _p(dz.buf), dz.ld, dz.off, _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
                                  _p(g[0]), _p(g[1]), _p(g[2]) if want_dbias else None, _p(ws.c1c2), _p(ws.acc),
                                  z.M, C, _stream()), "bn_relu_bwd")
@@ -451,7 +467,7 @@ def bn_relu_bwd_pool(src: PoolGrad, z: Act, dz: Act, st: BNState, ws: Workspace,
     if 3 * C > ws.acc.numel() or 2 * C > ws.c1c2.numel():
         raise UNetHipError("bn_relu_bwd_pool: workspace too small")
     g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
-    check(lib().unet_bn_relu_bwd_pool(z.dt, 1 if relu else 0, _p(dp.buf), _p(code), _p(dskip.buf), dskip.ld, dskip.off,
+    check(lib().unet_bn_relu_bwd_pool(z.dt, _bn_bwd_flags(st, relu), _p(dp.buf), _p(code), _p(dskip.buf), dskip.ld, dskip.off,
                                       _p(z.buf), z.ld, z.off, _p(dz.buf), dz.ld, dz.off,
                                       _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
                                       _p(g[0]), _p(g[1]), _p(g[2]) if want_dbias else None, _p(ws.c1c2), _p(ws.acc),

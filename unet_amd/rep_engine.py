@@ -79,7 +79,7 @@ class RepUNetEngine(UNetEngine):
                     st = ops.bn_finalize(rows, N * H * W, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
                                          B[bnp + ".num_batches_tracked"], REP_BN_MOMENTUM, EPS, ws)
                 else:
-                    st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], EPS)
+                    st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], EPS, for_backward=save)
                 zs.append(z); sts.append(st); names.append((wname, bnp, kh, kw))
         y = yout if yout is not None else ops.dense(N, H, W, Cout, dt, dev)
         ops.branch_sum_act(zs, [s.scale for s in sts], [s.shift for s in sts], self.norm == "group", y, relu=True)
