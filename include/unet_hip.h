@@ -138,6 +138,19 @@ int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, con
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* dbias,
                      float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
+/* unet_bn_relu_bwd without its two workspace arguments.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
+ * cannot allocate device memory -- code under HIP graph capture, tight serving / fine-tuning loops, harnesses that
+ * forbid hipMalloc.  The 3*C fp64 accumulators and 2*C fp32 coefficients live in a 64 KiB device array inside the library
+ * (one copy per GPU, held until the process ends), so C <= 2048 (larger C is rejected with an error; use unet_bn_relu_bwd).
+ * The call allocates and frees nothing.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race -- serialise them on one stream.  The first call on a device fetches the array's
+ * address (hipGetSymbolAddress), so make one warm-up call per device before capturing a graph.  Same results as
+ * unet_bn_relu_bwd (same kernels). */
+int unet_bn_relu_bwd_noalloc(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                             void* dz, int ldo, int ooff,
+                             const float* scale, const float* shift, const float* mean, const float* invstd,
+                             float* dgamma, float* dbeta, float* dbias,
+                             long long M, int C, void* stream);
 /* The same with dy = dskip + unpool(dpool, code): the backward of MaxPool2d(2,2) (models/unet.py:47) and the
  * skip-connection add evaluated inside both passes, so the gradient of an encoder level's output is never stored.
  * dpool [N,H/2,W/2,C] dense, code from unet_maxpool2x2_fwd, dskip a channel slice (lds, soff) of [N,H,W,*]. */

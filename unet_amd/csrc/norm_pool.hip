@@ -10,6 +10,8 @@
 // (/root/reference/models/unet.py:11-12,14-15) and nn.MaxPool2d(2,2) (models/unet.py:26,47).
 #include "common.h"
 
+#include <mutex>
+
 #define MAX_GRID 2048
 
 struct ChanMap {
@@ -705,6 +707,57 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
                                 float* dgamma, float* dbeta, float* dbias /* nullable */,
                                 float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
                                 long long M, int C, void* stream) {
+    return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
+                                   scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// unet_bn_relu_bwd for callers that cannot allocate (code under HIP graph capture, tight serving / fine-tuning loops,
+// harnesses that forbid hipMalloc): the two workspaces of unet_bn_relu_bwd (3*C fp64 accumulators + 2*C fp32
+// coefficients) live in a file-scope device array instead of caller memory.  Every GPU holds its own copy of the array
+// at its own address until the process ends (NOALLOC_SCRATCH_BYTES = 64 KiB).  The array's name is a host-side stand-in,
+// never a device address: the address is fetched once per device with hipGetSymbolAddress and only that pointer is
+// handed to memsets and kernels.
+#define NOALLOC_MAX_C 2048
+#define NOALLOC_ACC_BYTES (NOALLOC_MAX_C * 3 * sizeof(double))
+#define NOALLOC_SCRATCH_BYTES (NOALLOC_ACC_BYTES + NOALLOC_MAX_C * 2 * sizeof(float))
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+
+#define NOALLOC_MAX_DEVICES 64
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[NOALLOC_MAX_DEVICES];      // per device: that GPU's address of `scratch` (nullptr = not asked yet)
+
+static int noalloc_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        unet_set_error("bn_relu_bwd_noalloc: cannot identify the current device (%d)", dev);
+        return -2;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));     // with `dev` current: dev's copy
+        if (e != hipSuccess || ptr == nullptr) {
+            unet_set_error("bn_relu_bwd_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return -2;
+        }
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int unet_bn_relu_bwd_noalloc(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                                        void* dz, int ldo, int ooff,
+                                        const float* scale, const float* shift, const float* mean, const float* invstd,
+                                        float* dgamma, float* dbeta, float* dbias /* nullable */,
+                                        long long M, int C, void* stream) {
+    UNET_CHECK(C > 0 && C <= NOALLOC_MAX_C, "bn_relu_bwd_noalloc: C=%d exceeds the built-in scratch (at most %d channels); "
+               "use unet_bn_relu_bwd with caller workspaces", C, NOALLOC_MAX_C);
+    void* ptr = nullptr;
+    if (int rc = noalloc_scratch(&ptr)) return rc;
+    double* acc_ws = (double*)ptr;                                             // 3*C doubles, cleared by the shared implementation
+    float* c1c2_ws = (float*)((unsigned char*)ptr + NOALLOC_ACC_BYTES);        // 2*C floats, fully rewritten before they are read
     return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
                                    scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
 }
