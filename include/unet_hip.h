@@ -97,13 +97,14 @@ int unet_fold_bn_conv(const float* w, const float* bias, const float* gamma, con
  * utils/builders.py:143-146, as multi-tensor kernels over fp32 tensors.  The tensor lists are HOST
  * arrays of device pointers.  unet_grad_sumsq writes one fp64 partial per 16384-element chunk
  * (unet_mt_blocks of them); unet_grad_norm_finalize sums them in a fixed order and writes
- * norm_out[0] = ||g||_2 and norm_out[1] = min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_'s
- * coefficient) on the device.  unet_adamw_step multiplies the gradients by norm_out[1] (NULL: no
+ * norm_out[0] = ||grad_scale*g||_2 and norm_out[1] = grad_scale * min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_'s
+ * coefficient) on the device; grad_scale = 1 normally, 1/world when the tensors hold the all-reduced SUM of the ranks'
+ * gradients (train.py:143 DDP averages them): the averaging then costs no pass of its own.  unet_adamw_step multiplies the gradients by norm_out[1] (NULL: no
  * clipping; write_grads: store the clipped gradients back as clip_grad_norm_ does) and applies
  * torch.optim.AdamW's update for step number `step` (>= 1) to every tensor. */
 int unet_mt_blocks(int nt, const long long* numel);
 int unet_grad_sumsq(int nt, const void* const* grads, const long long* numel, double* partials, void* stream);
-int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float* norm_out, void* stream);
+int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float grad_scale, float* norm_out, void* stream);
 int unet_adamw_step(int nt, void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                     const long long* numel, const float* norm_out, int write_grads, double lr, double beta1,
                     double beta2, double eps, double weight_decay, long long step, void* stream);
@@ -227,6 +228,15 @@ int unet_fold_asymm(int k, int O, int I, const float* w_sq, const float* w_ve, c
                     const float* ve_w, const float* ve_b, const float* ve_rm, const float* ve_rv,
                     const float* ho_w, const float* ho_b, const float* ho_rm, const float* ho_rv,
                     float eps, float* out_w, float* out_b, void* stream);
+/* unet_fold_asymm with std = sqrt(running_var + eps) supplied per branch (length O each).  The sqrt is the only step of
+ * mergeBN (models/reparm_unet.py:29) that torch's CPU backend does not round correctly (MKL VML), so the IEEE fold above
+ * differs from a torch-CPU fold in ~1 % of the elements by one ulp; with the reference host's own sqrt handed in, the
+ * result equals the reference's mergedConv weights and biases bit for bit. */
+int unet_fold_asymm_std(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,
+                        const float* sq_w, const float* sq_b, const float* sq_rm, const float* sq_rv, const float* sq_std,
+                        const float* ve_w, const float* ve_b, const float* ve_rm, const float* ve_rv, const float* ve_std,
+                        const float* ho_w, const float* ho_b, const float* ho_rm, const float* ho_rv, const float* ho_std,
+                        float* out_w, float* out_b, void* stream);
 int unet_fold_embed_add(int K, int k, int O, int I, float* target_w, const float* src_w, float* target_b,
                         const float* src_b, void* stream);
 

@@ -83,6 +83,27 @@ def test_dataset_reads_reference_layout(tmp_path):
     assert imgs.shape == (3, 8, 8) and imgs.dtype == torch.float32 and masks.dtype == torch.uint8 and len(augs) == 3
 
 
+def test_collate_runs_inside_dataloader_workers(tmp_path):
+    """The documented configuration: DataLoader(num_workers=2, collate_fn=device_collate).  The collate function runs
+    in forked worker processes, so it must hand back plain (unpinned) CPU tensors and never touch the GPU runtime."""
+    from torch.utils.data import DataLoader
+    from unet_amd.data import REGISTRY, device_collate
+    for split in ("train", "val"):
+        for sub in ("images", "masks"):
+            os.makedirs(tmp_path / split / sub)
+        for i in range(6):
+            img, mask = make_slice(8, 8, i)
+            np.save(tmp_path / split / "images" / f"p0_slice_{i:03d}.npy", img)
+            np.save(tmp_path / split / "masks" / f"p0_slice_{i:03d}.npy", mask)
+    tr, _ = REGISTRY["ct_segmentation"](str(tmp_path), image_size=8)
+    seen = 0
+    for imgs, masks, augs in DataLoader(tr, batch_size=4, collate_fn=device_collate, num_workers=2):
+        assert imgs.dtype == torch.float32 and masks.dtype == torch.uint8 and imgs.shape[1:] == (8, 8)
+        assert not imgs.is_pinned() and not imgs.is_cuda and len(augs) == imgs.shape[0]
+        seen += imgs.shape[0]
+    assert seen == 6
+
+
 def test_theta_matches_oracle():
     from unet_amd.data.ct_device import rotation_theta
     for ang in (-15.0, -3.3, 0.0, 7.5, 14.999):

@@ -414,16 +414,28 @@ def test_argmax_ensemble_metrics_vs_reference_golden(dev):
     assert torch.equal(ops.argmax(l1).cpu(), g["pred1"])          # ties -> lowest class index
     assert torch.equal(ops.argmax(l2).cpu(), g["pred2"])
     pred = ops.ensemble_fuse(l1, l2, float(g["entropy_thresh"])).cpu()
-    # bit-exact wherever the decision is not within float rounding of a boundary
+    # The rule (eval_ensemble.py:77-99 per pixel) is discontinuous in two places only: |e1-e2| crossing the threshold
+    # and a tie of the fused probabilities.  A pixel within float rounding of either may legitimately fall on the
+    # other side of it; everywhere else the integer output must equal the reference's bit for bit.
     p1, p2 = torch.softmax(g["logits1"], 1), torch.softmax(g["logits2"], 1)
     e1, e2 = loss_ref.entropy(p1), loss_ref.entropy(p2)
     w1, w2 = 1 / (e1 + 1e-8), 1 / (e2 + 1e-8)
     pe = (w1[:, None] * p1 + w2[:, None] * p2) / (w1 + w2)[:, None]
     srt = pe.sort(1, descending=True).values
-    fragile = ((e1 - e2).abs() - 0.6).abs() < 1e-5
-    fragile |= (srt[:, 0] - srt[:, 1]) < 1e-6
-    fragile |= (e1 - e2).abs() < 1e-6
-    assert fragile.float().mean() < 0.2
+    near_thresh = ((e1 - e2).abs() - 0.6).abs() < 1e-5
+    near_tie = (srt[:, 0] - srt[:, 1]) < 1e-6
+    # the fixture's deliberate exact ties have an ANALYTIC answer and are checked unmasked:
+    #   row 12: both models output logits (0, 0): p1 = p2 = (.5, .5), e1 = e2, fused (.5, .5) -> argmax tie -> class 0
+    #   row 13: model 1 outputs (0, 0): it adds the same weight to both classes, so whichever branch is taken the
+    #           prediction is model 2's argmax
+    assert torch.equal(pred[:, 12, :], torch.zeros_like(pred[:, 12, :]))
+    assert torch.equal(pred[:, 13, :], g["logits2"][:, :, 13, :].argmax(1))
+    assert torch.equal(pred[:, 12:14, :], g["pred_ens"][:, 12:14, :])
+    near_tie[:, 12:14, :] = False
+    fragile = near_thresh | near_tie
+    n_frag, n_bad = int(fragile.sum()), int((pred[fragile] != g["pred_ens"][fragile]).sum())
+    print(f"ensemble: {n_frag} of {fragile.numel()} pixels within rounding of a decision boundary, {n_bad} of them differ from the reference")
+    assert n_frag <= 0.01 * fragile.numel()
     assert torch.equal(pred[~fragile], g["pred_ens"][~fragile])
     nan_l = l1.clone(); nan_l[0, 1, 0, 0] = float("nan")
     assert int(ops.argmax(nan_l)[0, 0, 0]) == int(nan_l.cpu().argmax(1)[0, 0, 0])
@@ -454,3 +466,34 @@ def test_rows_colsum_matches_torch(dev, nrows):
     assert torch.equal(got, again)                       # fixed summation order
     with pytest.raises(ops.UNetHipError):
         ops.rows_colsum(rows, 2 * f, ctot, 2)            # columns past the end of the row
+
+
+@pytest.mark.parametrize("C", [2, 3])
+def test_ensemble_fuse_large_vs_oracle(dev, C):
+    """65 k pixels of mixed-confidence logits (plus exact-tie rows) against the pinned oracle (oracle/loss_ref.py
+    ensemble_fuse = eval_ensemble.py:77-99 per pixel).  Integer output: bit-exact except within float rounding of the
+    two discontinuities; the size of that set and the mismatches inside it are reported."""
+    ops = ops_mod()
+    from oracle import loss_ref
+    g = torch.Generator().manual_seed(77 + C)
+    N, H, W = 4, 128, 128
+    l1 = torch.randn(N, C, H, W, generator=g) * torch.rand(N, 1, H, W, generator=g) * 4.0
+    l2 = torch.randn(N, C, H, W, generator=g) * torch.rand(N, 1, H, W, generator=g) * 4.0
+    l1[:, :, 0:4, :] = 0.0                       # model 1 exactly undecided on four rows
+    l2[:, :, 2:6, :] = 0.0                       # model 2 on four rows, two of them shared
+    ref = loss_ref.ensemble_fuse(l1, l2, 0.6)
+    pred = ops.ensemble_fuse(l1.to(dev), l2.to(dev), 0.6).cpu()
+    p1, p2 = torch.softmax(l1, 1), torch.softmax(l2, 1)
+    e1, e2 = loss_ref.entropy(p1), loss_ref.entropy(p2)
+    w1, w2 = 1 / (e1 + 1e-8), 1 / (e2 + 1e-8)
+    pe = (w1[:, None] * p1 + w2[:, None] * p2) / (w1 + w2)[:, None]
+    srt = pe.sort(1, descending=True).values
+    fragile = (((e1 - e2).abs() - 0.6).abs() < 1e-5) | ((srt[:, 0] - srt[:, 1]) < 1e-6)
+    fragile[:, 0:6, :] = False                   # the exact ties are analytic and stay in the checked set
+    assert torch.equal(pred[:, 2:4, :], torch.zeros_like(pred[:, 2:4, :]))              # both undecided -> class 0
+    assert torch.equal(pred[:, 0:2, :], l2[:, :, 0:2, :].argmax(1))                    # only model 1 undecided
+    assert torch.equal(pred[:, 4:6, :], l1[:, :, 4:6, :].argmax(1))                    # only model 2 undecided
+    n_frag, n_bad = int(fragile.sum()), int((pred[fragile] != ref[fragile]).sum())
+    print(f"ensemble C={C}: {n_frag} of {fragile.numel()} pixels within rounding of a decision boundary, {n_bad} of them differ")
+    assert n_frag <= 1e-3 * fragile.numel()
+    assert torch.equal(pred[~fragile], ref[~fragile])

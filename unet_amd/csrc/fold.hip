@@ -10,7 +10,8 @@
 //   across kernel sizes: target = clone(largest); target[centre kxk] += smaller, ascending; bias likewise
 #include "common.h"
 
-struct BNv { const float* w; const float* b; const float* rm; const float* rv; };
+// std: optional per-channel sqrt(running_var + eps) computed by the caller (unet_fold_asymm_std); NULL = computed here
+struct BNv { const float* w; const float* b; const float* rm; const float* rv; const float* std; };
 
 // Correctly rounded fp32 sqrt and divide: evaluate in fp64 (IEEE-correct on gfx950) and round once more to
 // fp32.  With 53 >= 2*24+2 significand bits the double rounding is innocuous for sqrt and divide, so the
@@ -19,11 +20,11 @@ __device__ __forceinline__ float sqrt_cr(float x) { return (float)sqrt((double)x
 __device__ __forceinline__ float div_cr(float a, float b) { return (float)((double)a / (double)b); }
 
 __device__ __forceinline__ float bn_t(const BNv& bn, int c, float eps) {
-    const float std_ = sqrt_cr(bn.rv[c] + eps);
+    const float std_ = bn.std != nullptr ? bn.std[c] : sqrt_cr(bn.rv[c] + eps);
     return div_cr(bn.w[c], std_);
 }
 __device__ __forceinline__ float bn_b(const BNv& bn, int c, float eps) {
-    const float std_ = sqrt_cr(bn.rv[c] + eps);
+    const float std_ = bn.std != nullptr ? bn.std[c] : sqrt_cr(bn.rv[c] + eps);
     return bn.b[c] - div_cr(bn.rm[c] * bn.w[c], std_);
 }
 
@@ -62,18 +63,38 @@ __global__ void fold_embed_add_kernel(int K, int k, int O, int I, float* __restr
         tb[o] = tb[o] + sb[o];
 }
 
+static int fold_asymm_launch(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,
+                             const BNv& a, const BNv& b, const BNv& c, float eps, float* out_w, float* out_b, void* stream) {
+    UNET_CHECK(k >= 1 && (k & 1) && O > 0 && I > 0, "fold: kernel size must be odd");
+    UNET_CHECK(w_sq && w_ve && w_ho && out_w && out_b && a.w && a.b && a.rm && a.rv && b.w && b.b && b.rm && b.rv && c.w && c.b && c.rm && c.rv,
+               "fold: null argument");
+    const size_t total = (size_t)O * I * k * k;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fold_asymm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, O, I, w_sq, w_ve, w_ho, a, b, c, eps, out_w, out_b);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int unet_fold_asymm(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,
                                const float* sq_w, const float* sq_b, const float* sq_rm, const float* sq_rv,
                                const float* ve_w, const float* ve_b, const float* ve_rm, const float* ve_rv,
                                const float* ho_w, const float* ho_b, const float* ho_rm, const float* ho_rv,
                                float eps, float* out_w, float* out_b, void* stream) {
-    UNET_CHECK(k >= 1 && (k & 1) && O > 0 && I > 0, "fold: kernel size must be odd");
-    const size_t total = (size_t)O * I * k * k;
-    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
-    BNv a{sq_w, sq_b, sq_rm, sq_rv}, b{ve_w, ve_b, ve_rm, ve_rv}, c{ho_w, ho_b, ho_rm, ho_rv};
-    hipLaunchKernelGGL(fold_asymm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, k, O, I, w_sq, w_ve, w_ho, a, b, c, eps, out_w, out_b);
-    UNET_LAUNCH_CHECK();
-    return 0;
+    return fold_asymm_launch(k, O, I, w_sq, w_ve, w_ho, BNv{sq_w, sq_b, sq_rm, sq_rv, nullptr}, BNv{ve_w, ve_b, ve_rm, ve_rv, nullptr},
+                             BNv{ho_w, ho_b, ho_rm, ho_rv, nullptr}, eps, out_w, out_b, stream);
+}
+
+// The same with std = sqrt(running_var + eps) supplied per branch: the one step of the reference's fold that is not an
+// IEEE-exact operation on its own host (torch's CPU sqrt is MKL VML, up to one ulp off), a vector of <= 1024 floats.
+// A caller that hands in the reference host's own sqrt gets the reference's folded weights bit for bit.
+extern "C" int unet_fold_asymm_std(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,
+                                   const float* sq_w, const float* sq_b, const float* sq_rm, const float* sq_rv, const float* sq_std,
+                                   const float* ve_w, const float* ve_b, const float* ve_rm, const float* ve_rv, const float* ve_std,
+                                   const float* ho_w, const float* ho_b, const float* ho_rm, const float* ho_rv, const float* ho_std,
+                                   float* out_w, float* out_b, void* stream) {
+    UNET_CHECK(sq_std && ve_std && ho_std, "fold_asymm_std: the three std vectors are required");
+    return fold_asymm_launch(k, O, I, w_sq, w_ve, w_ho, BNv{sq_w, sq_b, sq_rm, sq_rv, sq_std}, BNv{ve_w, ve_b, ve_rm, ve_rv, ve_std},
+                             BNv{ho_w, ho_b, ho_rm, ho_rv, ho_std}, 0.f, out_w, out_b, stream);
 }
 
 extern "C" int unet_fold_embed_add(int K, int k, int O, int I, float* target_w, const float* src_w, float* target_b,

@@ -69,10 +69,12 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(MTNormTable tb, double* _
     if (threadIdx.x == 0) partials[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// One workgroup, fixed summation order: bitwise reproducible total.  out[0] = ||g||_2, out[1] = the
-// clip coefficient min(1, max_norm / (norm + 1e-6)) of torch.nn.utils.clip_grad_norm_.
+// One workgroup, fixed summation order: bitwise reproducible total.  The tensors hold grad_scale^-1 times the gradients
+// that are to be clipped (data parallel: the all-reduced SUM over W ranks, grad_scale = 1/W; otherwise 1):
+// out[0] = ||grad_scale * g||_2, out[1] = grad_scale * min(1, max_norm / (norm + 1e-6)) -- clip_grad_norm_'s coefficient
+// with the averaging folded in, so the update kernel's one multiply does both.
 __global__ __launch_bounds__(256) void mt_norm_finalize_kernel(const double* __restrict__ partials, int n, float max_norm,
-                                                               float* __restrict__ out) {
+                                                               float grad_scale, float* __restrict__ out) {
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
     __shared__ double red[4];
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(256) void mt_norm_finalize_kernel(const double* __r
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        const float norm = (float)(sqrt((red[0] + red[1]) + (red[2] + red[3])) * (double)grad_scale);
         const float coef = max_norm / (norm + 1e-6f);
         out[0] = norm;
-        out[1] = coef < 1.0f ? coef : 1.0f;
+        out[1] = (coef < 1.0f ? coef : 1.0f) * grad_scale;
     }
 }
 
@@ -245,9 +247,10 @@ extern "C" int unet_grad_sumsq(int nt, const void* const* grads, const long long
     return 0;
 }
 
-extern "C" int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float* norm_out, void* stream) {
+extern "C" int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float grad_scale, float* norm_out, void* stream) {
     UNET_CHECK(nblocks >= 0 && norm_out && (nblocks == 0 || partials), "grad_norm_finalize: null argument");
-    hipLaunchKernelGGL(mt_norm_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nblocks, max_norm, norm_out);
+    UNET_CHECK(grad_scale > 0.f, "grad_norm_finalize: grad_scale must be positive");
+    hipLaunchKernelGGL(mt_norm_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, nblocks, max_norm, grad_scale, norm_out);
     UNET_LAUNCH_CHECK();
     return 0;
 }

@@ -73,15 +73,14 @@ class CT_NpyDataset(torch.utils.data.Dataset):
 
 
 def device_collate(samples):
-    """-> (images float32 [N,H0,W0], masks uint8 [N,H0,W0], [(hflip, vflip, angle)]) in pinned host memory.
-    Masks with values above 255 are saturated to 255 first (only `> 0` survives the transform)."""
+    """-> (images float32 [N,H0,W0], masks uint8 [N,H0,W0], [(hflip, vflip, angle)]) as plain CPU tensors.
+    Masks with values above 255 are saturated to 255 first (only `> 0` survives the transform).
+    It runs inside DataLoader worker processes (num_workers > 0), which must never touch the GPU runtime, so it does not
+    pin: ask the loader for that (`DataLoader(..., pin_memory=True)` pins in the parent's pin thread)."""
     imgs = np.stack([np.asarray(s[0], dtype=np.float32) for s in samples])
     masks = np.stack([np.minimum(np.asarray(s[1]), 255).astype(np.uint8) if np.asarray(s[1]).dtype != np.uint8
                       else np.asarray(s[1]) for s in samples])
-    ti, tm = torch.from_numpy(imgs), torch.from_numpy(masks)
-    if torch.cuda.is_available():
-        ti, tm = ti.pin_memory(), tm.pin_memory()
-    return ti, tm, [s[2] for s in samples]
+    return torch.from_numpy(imgs), torch.from_numpy(masks), [s[2] for s in samples]
 
 
 class DeviceCTPipeline:

@@ -54,7 +54,7 @@ class AsymmConvBlock(nn.Module):
     def forward(self, x):
         raise ops.UNetHipError("AsymmConvBlock is executed by ReparamUNet.forward on the HIP engine")
 
-    def mergeAsyKernels(self):
+    def mergeAsyKernels(self, sqrt="reference"):
         if self.mergedFlag:
             return
         if self.norm != "batch":
@@ -62,7 +62,7 @@ class AsymmConvBlock(nn.Module):
                                    "GroupNorm (the shipped default) is input-dependent and cannot be folded")
         w, b = ops.fold_asymm(self.kernel_size, self.convSq.weight.detach().contiguous(), self.convVe1.weight.detach().contiguous(),
                               self.convHo1.weight.detach().contiguous(), _bn_tuple(self.bnSq), _bn_tuple(self.bnVe1),
-                              _bn_tuple(self.bnHo1), self.bnSq.eps)
+                              _bn_tuple(self.bnHo1), self.bnSq.eps, sqrt=sqrt)
         k = self.kernel_size
         self.mergedConv = getConv2D(self.in_channels, self.out_channels, (k, k), self.stride, [self.padding, self.padding], bias=True)
         self.mergedConv.weight.data = w
@@ -88,11 +88,11 @@ class MultiConvBlock(nn.Module):
     def forward(self, x):
         raise ops.UNetHipError("MultiConvBlock is executed by ReparamUNet.forward on the HIP engine")
 
-    def mergeMulKernels(self):
+    def mergeMulKernels(self, sqrt="reference"):
         if self.mergedFlag:
             return
         for block in self.conv_list:
-            block.mergeAsyKernels()
+            block.mergeAsyKernels(sqrt)
         target_w = self.conv_list[-1].mergedConv.weight.data.clone()
         target_b = self.conv_list[-1].mergedConv.bias.data.clone()
         for i in range(len(self.conv_list) - 1):
@@ -187,12 +187,16 @@ class ReparamUNet(SlotCache, nn.Module):
             self.make_deploy_skeleton()
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
-    def switch_to_deploy(self):
-        """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels)."""
+    def switch_to_deploy(self, sqrt="reference"):
+        """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels).
+        sqrt="reference" (default): std = sqrt(running_var + eps) is taken with torch's CPU sqrt as the reference does
+        (models/reparm_unet.py:29), every other step is an exactly rounded fp32 operation in the reference's order, so
+        the result is torch.equal to the reference's fold on this host; sqrt="ieee": correctly rounded sqrt on the
+        device (identical on every host; differs from torch's MKL sqrt by one ulp for ~0.7 % of the channels)."""
         print("[ReparamUNet] Switching to deploy mode (fusing kernels)...")
         for module in list(self.modules()):
             if isinstance(module, MultiConvBlock):
-                module.mergeMulKernels()
+                module.mergeMulKernels(sqrt)
         self._engine._packed.clear()
         self.invalidate_slots()
         print("[ReparamUNet] Fusion complete.")

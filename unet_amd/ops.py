@@ -161,9 +161,9 @@ def mt_blocks(numels) -> int:
     return r
 
 
-def grad_norm(grads, max_norm: float, partials: torch.Tensor, norm_out: torch.Tensor):
-    """Global L2 norm of `grads` and clip_grad_norm_'s coefficient, on the device:
-    norm_out[0] = norm, norm_out[1] = min(1, max_norm / (norm + 1e-6))."""
+def grad_norm(grads, max_norm: float, partials: torch.Tensor, norm_out: torch.Tensor, grad_scale: float = 1.0):
+    """Global L2 norm of grad_scale*`grads` and clip_grad_norm_'s coefficient times grad_scale, on the device:
+    norm_out[0] = norm, norm_out[1] = grad_scale * min(1, max_norm / (norm + 1e-6))."""
     import ctypes
     _f32_list(grads, "grad_norm")
     n = len(grads)
@@ -173,7 +173,7 @@ def grad_norm(grads, max_norm: float, partials: torch.Tensor, norm_out: torch.Te
         raise UNetHipError("grad_norm: workspace too small")
     NA = (ctypes.c_longlong * n)(*numels)
     check(lib().unet_grad_sumsq(n, (ctypes.c_void_p * n)(*[g.data_ptr() for g in grads]), NA, _p(partials), _stream()), "grad_sumsq")
-    check(lib().unet_grad_norm_finalize(_p(partials), nb, float(max_norm), _p(norm_out), _stream()), "grad_norm_finalize")
+    check(lib().unet_grad_norm_finalize(_p(partials), nb, float(max_norm), float(grad_scale), _p(norm_out), _stream()), "grad_norm_finalize")
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, norm_out: Optional[torch.Tensor], write_grads: bool,
@@ -659,8 +659,13 @@ def gn_bwd(u: Act, z: Act, st: GNState, gamma: torch.Tensor):
     return dz, g[0], g[1]
 
 
-def fold_asymm(k, w_sq, w_ve, w_ho, bn_sq, bn_ve, bn_ho, eps=1e-5):
-    """One AsymmConvBlock -> (weight (O,I,k,k), bias (O)); bn_* = (weight, bias, running_mean, running_var)."""
+def fold_asymm(k, w_sq, w_ve, w_ho, bn_sq, bn_ve, bn_ho, eps=1e-5, sqrt="ieee"):
+    """One AsymmConvBlock -> (weight (O,I,k,k), bias (O)); bn_* = (weight, bias, running_mean, running_var).
+    sqrt="ieee": std = correctly rounded sqrt(running_var + eps) on the device (reproducible everywhere);
+    sqrt="reference": std is computed the way the reference computes it -- torch's CPU sqrt on this host (three vectors
+    of <= 1024 floats cross PCIe) -- so the folded tensors are torch.equal to what the reference's own
+    switch_to_deploy() produces on this host.
+    sqrt=callable: std = sqrt(cpu fp32 tensor running_var + eps) from the caller (e.g. another host's torch sqrt)."""
     ts = [w_sq, w_ve, w_ho, *bn_sq, *bn_ve, *bn_ho]
     _need_cuda(*ts)
     for t in ts:
@@ -671,6 +676,20 @@ def fold_asymm(k, w_sq, w_ve, w_ho, bn_sq, bn_ve, bn_ho, eps=1e-5):
         raise UNetHipError("fold: branch kernel shapes do not match")
     out_w = torch.empty((O, I, k, k), dtype=torch.float32, device=w_sq.device)
     out_b = torch.empty((O,), dtype=torch.float32, device=w_sq.device)
+    if sqrt == "reference" or callable(sqrt):
+        fn = torch.sqrt if sqrt == "reference" else sqrt
+        stds = [fn(bn[3].cpu() + eps).to(device=w_sq.device, dtype=torch.float32).contiguous()
+                for bn in (bn_sq, bn_ve, bn_ho)]                                                   # mergeBN: (running_var + eps).sqrt()
+        for sd in stds:
+            if sd.numel() != O:
+                raise UNetHipError("fold: the sqrt callable must return one value per channel")
+        args = []
+        for bn, sd in zip((bn_sq, bn_ve, bn_ho), stds):
+            args += [_p(t) for t in bn] + [_p(sd)]
+        check(lib().unet_fold_asymm_std(k, O, I, _p(w_sq), _p(w_ve), _p(w_ho), *args, _p(out_w), _p(out_b), _stream()), "fold_asymm_std")
+        return out_w, out_b
+    if sqrt != "ieee":
+        raise UNetHipError(f"fold: sqrt must be 'ieee' or 'reference', got {sqrt!r}")
     check(lib().unet_fold_asymm(k, O, I, _p(w_sq), _p(w_ve), _p(w_ho), *[_p(t) for t in bn_sq], *[_p(t) for t in bn_ve],
                                 *[_p(t) for t in bn_ho], float(eps), _p(out_w), _p(out_b), _stream()), "fold_asymm")
     return out_w, out_b

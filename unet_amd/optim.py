@@ -78,12 +78,15 @@ class FusedAdamW(torch.optim.AdamW):
         return work
 
     # ------------------------------------------------------------------ API
-    def clip_and_step(self, parameters: Iterable[torch.Tensor], max_norm: float) -> Optional[torch.Tensor]:
+    def clip_and_step(self, parameters: Iterable[torch.Tensor], max_norm: float, grad_scale: float = 1.0) -> Optional[torch.Tensor]:
         """clip_grad_norm_(parameters, max_norm) followed by step(), without a host sync.
-        Returns the total gradient norm (0-dim device tensor), as clip_grad_norm_ does."""
+        Returns the total gradient norm (0-dim device tensor), as clip_grad_norm_ does.
+        grad_scale: the .grad tensors hold 1/grad_scale times the gradients (data parallel hands over the all-reduced
+        SUM with grad_scale = 1/world); norm, clipping and update are those of grad_scale*grad, and the clipped
+        gradients written back are the averaged ones."""
         if isinstance(parameters, torch.Tensor):
             parameters = [parameters]
-        self._pending_clip = ([p for p in parameters if p.grad is not None], float(max_norm))
+        self._pending_clip = ([p for p in parameters if p.grad is not None], float(max_norm), float(grad_scale))
         self._clip_norm = None
         try:
             self.step()
@@ -101,6 +104,11 @@ class FusedAdamW(torch.optim.AdamW):
         self._pending_clip = None
         work = self._collect()
         clip_ok = clip is None or all(self._tensor_ok(p.grad) for p in clip[0])
+        if clip is not None and clip[2] != 1.0 and (work is None or not clip_ok or len({p.grad.device for p in clip[0]}) > 1
+                                                    or {id(p) for p in clip[0]} != {id(p) for _, _, pl in (work or []) for p in pl}):
+            for p in clip[0]:                           # a path below that cannot fold the scale: apply it first
+                p.grad.mul_(clip[2])
+            clip = (clip[0], clip[1], 1.0)
         if work is None or not clip_ok:
             if clip is not None and clip[0]:
                 self._clip_norm = torch.nn.utils.clip_grad_norm_(clip[0], clip[1])
@@ -114,7 +122,7 @@ class FusedAdamW(torch.optim.AdamW):
                 self._clip_norm = torch.nn.utils.clip_grad_norm_(clip[0], clip[1])
             else:
                 partials, norm_out = self._ws(dev, ops.mt_blocks([g.numel() for g in grads]))
-                ops.grad_norm(grads, clip[1], partials, norm_out)
+                ops.grad_norm(grads, clip[1], partials, norm_out, clip[2])
                 self._clip_norm = norm_out[0].clone()
                 stepped = {id(p) for _, _, plist in work for p in plist}
                 for p in clip[0]:                       # clipped but not stepped by this optimizer

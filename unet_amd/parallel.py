@@ -19,6 +19,9 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+ALIGN = 64          # elements: 256 bytes for fp32 gradients
+
+
 class BucketReducer:
     """Average named gradient tensors across the process group in arrival-order buckets."""
 
@@ -34,6 +37,8 @@ class BucketReducer:
         self._cur: List[torch.Tensor] = []
         self._cur_bytes = 0
         self.buckets_launched = 0
+        self._flat_cache: Dict[tuple, torch.Tensor] = {}      # (bucket index in this backward, numel, dtype, device) -> flat buffer
+        self._bucket_idx = 0
 
     def add(self, names: List[str], tensors: List[torch.Tensor]):
         for n, t in zip(names, tensors):
@@ -49,11 +54,27 @@ class BucketReducer:
         if not self._cur:
             return
         dtype = self.comm_dtype or self._cur[0].dtype
-        flat = torch.cat([t.reshape(-1).to(dtype) for t in self._cur])
+        # the bucket layout repeats every step (fixed arrival order), so the flat buffers are allocated once and the
+        # gather writes into them; p.grad of the previous step (views of these buffers, as with DDP's
+        # gradient_as_bucket_view) is dropped by zero_grad(set_to_none=True) before they are written again
+        # every tensor starts on a 256-byte boundary of the bucket, as a fresh allocation would: the multi-tensor
+        # norm / AdamW kernels pick their vector path by alignment, and the clip norm must not depend (in its last
+        # bit) on whether p.grad is a bucket view or its own allocation
+        offs, numel = [], 0
+        for t in self._cur:
+            offs.append(numel)
+            numel += (t.numel() + ALIGN - 1) // ALIGN * ALIGN
+        key = (self._bucket_idx, tuple(offs), numel, dtype, self._cur[0].device)
+        flat = self._flat_cache.get(key)
+        if flat is None:
+            flat = self._flat_cache[key] = torch.zeros(numel, dtype=dtype, device=self._cur[0].device)
+        views = [flat[o:o + t.numel()] for o, t in zip(offs, self._cur)]
+        torch._foreach_copy_(views, [t.reshape(-1) for t in self._cur])
+        self._bucket_idx += 1
         work = None
         if self.collective:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-        self._pending.append((self._cur_names, [t.shape for t in self._cur], flat, work))
+        self._pending.append((self._cur_names, [t.shape for t in self._cur], offs, flat, work))
         self._cur_names, self._cur, self._cur_bytes = [], [], 0
         self.buckets_launched += 1
 
@@ -61,22 +82,22 @@ class BucketReducer:
         """All gradients of this backward pass have been handed over: launch the partial last bucket."""
         self._launch()
 
-    def finish(self) -> Dict[str, torch.Tensor]:
-        """Wait for every bucket; returns {name: averaged gradient view}."""
+    def finish(self, average: bool = True) -> Dict[str, torch.Tensor]:
+        """Wait for every bucket; returns {name: gradient view}: the average over ranks, or with average=False the SUM
+        (the caller folds 1/world into its clip coefficient and saves the pass)."""
         self._launch()
+        self._bucket_idx = 0
         out: Dict[str, torch.Tensor] = {}
-        for names, shapes, flat, work in self._pending:
+        for names, shapes, offs, flat, work in self._pending:
             if work is not None:
                 work.wait()
-            if self.world > 1:
+            if self.world > 1 and average:
                 flat.div_(self.world)
-            off = 0
-            for n, s in zip(names, shapes):
+            for n, s, off in zip(names, shapes, offs):
                 k = 1
                 for d in s:
                     k *= d
                 out[n] = flat[off:off + k].view(s)
-                off += k
         self._pending = []
         return out
 
@@ -100,6 +121,13 @@ class DataParallel(nn.Module):
         self._buf_flats: List = []          # [(flat tensor, [buffers that are views of it])] per dtype
         if self.collective:
             self._broadcast([p.data for p in module.parameters()])
+            # the copies above went through .data (no version bump): drop every image the engine derived from the old
+            # weights (a forward before wrapping would otherwise leave ranks > 0 computing with their pre-broadcast weights)
+            torch.autograd.graph.increment_version(list(module.parameters()))
+            eng = getattr(module, "_engine", None)
+            if eng is not None:
+                eng._packed.clear()
+                eng._folded.clear()
             self._sync_buffers()
 
     def _src(self):
@@ -158,9 +186,10 @@ class DataParallel(nn.Module):
             self._sync_buffers()
         return self.module(*args, **kwargs)
 
-    def finish_grad_sync(self):
-        """Called after loss.backward(): p.grad <- average over ranks."""
-        avg = self.reducer.finish()
+    def finish_grad_sync(self, average: bool = True):
+        """Called after loss.backward(): p.grad <- average over ranks.  average=False leaves the SUM in p.grad and
+        returns the factor still owed (1/world); step_batch hands it to FusedAdamW.clip_and_step(grad_scale=...)."""
+        avg = self.reducer.finish(average)
         for n, g in avg.items():
             p = self._params[n]
             if p.grad is None:
@@ -169,3 +198,4 @@ class DataParallel(nn.Module):
                 p.grad = g                  # a contiguous view of the reduced bucket (DDP's gradient_as_bucket_view)
             else:
                 p.grad.copy_(g)             # communication dtype differs from the gradient's
+        return 1.0 if (average or self.world <= 1) else 1.0 / self.world

@@ -43,14 +43,20 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
         main_loss = trainer.loss_fn(logits, y)
 
     scaler.scale(main_loss).backward()
-    sync = getattr(trainer.model, "finish_grad_sync", None)
-    if sync is not None:          # data-parallel wrapper: wait for the bucketed all-reduces
-        sync()
-
     fused = getattr(trainer.optimizer, "clip_and_step", None)
-    if fused is not None and not scaler.is_enabled() and trainer.grad_clip > 0:
+    use_fused = fused is not None and not scaler.is_enabled() and trainer.grad_clip > 0
+    sync = getattr(trainer.model, "finish_grad_sync", None)
+    grad_scale = 1.0
+    if sync is not None:          # data-parallel wrapper: wait for the bucketed all-reduces
+        # with the fused tail the division by the world size rides on the clip coefficient (no pass of its own)
+        grad_scale = sync(average=not use_fused) or 1.0
+
+    if use_fused:
         # unet_amd.optim.FusedAdamW: norm -> clip -> AdamW in two multi-tensor passes, no host sync
-        fused(trainer.model.parameters(), trainer.grad_clip)
+        if grad_scale != 1.0:
+            fused(trainer.model.parameters(), trainer.grad_clip, grad_scale=grad_scale)
+        else:
+            fused(trainer.model.parameters(), trainer.grad_clip)
     else:
         if trainer.grad_clip > 0:
             scaler.unscale_(trainer.optimizer)
