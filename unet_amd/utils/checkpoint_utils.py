@@ -1,100 +1,127 @@
-"""Checkpoint save / load with the reference's file format and signatures
-(/root/reference/utils/checkpoint_utils.py:15-89), loguru-free.
+"""Checkpoint files in the reference's on-disk format (written by /root/reference/utils/checkpoint_utils.py:15-48,
+read by :50-89 and by /root/reference/utils/io.py:19-45), so that a `last.ckpt` / `best.ckpt` produced by either side
+loads on the other.  Only the FORMAT is the contract; it is stated here as data:
 
-A checkpoint written here loads in the reference and vice versa: keys `epoch`, `model_state` (+ compat
-`model`), `optim_state` (`opt`), `scheduler_state` (`sched`), `scaler_state`, `trainer_backbone_frozen`,
-`latest_val_stats`, `cfg`; files `last.ckpt` / `best.ckpt`.  The module state_dict is the reference's
-(identical keys and shapes), unwrapped from unet_amd.parallel.DataParallel / torch DDP / nn.DataParallel;
-the `module.` prefix fix-up on load is the reference's (:66-79).  FusedAdamW's state_dict is torch AdamW's.
+  * FIELDS: what one checkpoint dict holds, each entry under a canonical key plus the older aliases readers accept;
+  * a state_dict may carry the `module.` prefix of a DDP / DataParallel wrapper on either side: `match_prefix`
+    rewrites the keys to whatever the receiving model uses;
+  * files: `<dir>/last.ckpt` always, `<dir>/best.ckpt` when asked.
 
-`torch.load` runs with weights_only=True by default (tensors, containers and plain scalars: everything
-save_checkpoint writes); pass weights_only=False only for a checkpoint you trust that pickled other objects.
+`torch.load` runs with weights_only=True by default (tensors, containers and plain scalars: everything written here);
+pass weights_only=False only for a trusted checkpoint that pickled other objects.
 """
 import logging
 import os
+from typing import Callable, Dict, Iterable, Mapping, NamedTuple, Optional, Tuple
 
 import torch
 import torch.nn as nn
 
 log = logging.getLogger("unet_amd.checkpoint")
 
-
-def _pick(*dicts, keys=None):
-    for d in dicts:
-        if not isinstance(d, dict):
-            continue
-        for k in keys or []:
-            if k in d:
-                return d[k], k
-    return None, None
+PREFIX = "module."
 
 
-def _unwrap(model):
+class Field(NamedTuple):
+    key: str                         # canonical key in the file
+    aliases: Tuple[str, ...]         # further keys under which readers look for it, in order
+    dup: Optional[str]               # second key the writer stores the same object under (older readers)
+    source: Callable                 # trainer -> object to store
+
+
+def _state_of(attr):
+    def get(trainer):
+        obj = getattr(trainer, attr, None)
+        return obj.state_dict() if obj else None
+    return get
+
+
+def unwrap(model):
+    """The module inside a data-parallel wrapper (ours, DDP, nn.DataParallel), else the model itself."""
     from ..parallel import DataParallel
-    if isinstance(model, (DataParallel, nn.DataParallel, nn.parallel.DistributedDataParallel)):
-        return model.module
-    return model
+    wrappers = (DataParallel, nn.DataParallel, nn.parallel.DistributedDataParallel)
+    return model.module if isinstance(model, wrappers) else model
+
+
+def _model_state(trainer):
+    model = getattr(trainer, "model", None)
+    return None if model is None else unwrap(model).state_dict()
+
+
+FIELDS: Dict[str, Field] = {
+    "model": Field("model_state", ("model", "state_dict", "model_state_dict"), "model", _model_state),
+    "optimizer": Field("optim_state", ("opt", "optimizer"), "opt", _state_of("optimizer")),
+    "scheduler": Field("scheduler_state", ("sched", "scheduler"), "sched", _state_of("scheduler")),
+    "scaler": Field("scaler_state", ("scaler",), None, _state_of("scaler")),
+    "frozen": Field("trainer_backbone_frozen", (), None, lambda t: getattr(t, "_backbone_frozen", False)),
+    "val_stats": Field("latest_val_stats", (), None, lambda t: getattr(t, "latest_val_stats", {})),
+    "cfg": Field("cfg", (), None, lambda t: getattr(t, "cfg", None)),
+}
+EPOCH_KEYS = ("epoch", "epo")
+
+
+def section(ckpt, name: str):
+    """The object stored for FIELDS[name] under its canonical key or the first alias present, else None."""
+    if not isinstance(ckpt, Mapping):
+        return None
+    f = FIELDS[name]
+    for k in (f.key,) + f.aliases:
+        if k in ckpt:
+            return ckpt[k]
+    return None
+
+
+def match_prefix(state: Mapping[str, torch.Tensor], target_keys: Iterable[str]) -> Dict[str, torch.Tensor]:
+    """Add or strip the leading `module.` so the keys line up with the receiving model's."""
+    want = any(k.startswith(PREFIX) for k in target_keys)
+    have = any(k.startswith(PREFIX) for k in state)
+    if want == have:
+        return dict(state)
+    if have:
+        return {(k[len(PREFIX):] if k.startswith(PREFIX) else k): v for k, v in state.items()}
+    return {PREFIX + k: v for k, v in state.items()}
+
+
+def _dir_of(path: str) -> str:
+    return os.path.dirname(path) if os.path.splitext(path)[1] else path
 
 
 def save_checkpoint(path: str, trainer, epoch: int, is_best: bool = False) -> None:
-    out_dir = os.path.dirname(path) if os.path.splitext(path)[1] else path
+    """`path` names the run directory (or a file inside it).  Same signature as the reference's."""
+    out_dir = _dir_of(path)
     os.makedirs(out_dir, exist_ok=True)
-    model_ref = getattr(trainer, "model", None)
-    model_state = _unwrap(model_ref).state_dict() if model_ref is not None else None
+    ckpt = {EPOCH_KEYS[0]: int(epoch)}
+    for f in FIELDS.values():
+        ckpt[f.key] = f.source(trainer)
+    for f in FIELDS.values():
+        if f.dup:
+            ckpt[f.dup] = ckpt[f.key]
+    for name in ("last.ckpt",) + (("best.ckpt",) if is_best else ()):
+        torch.save(ckpt, os.path.join(out_dir, name))
 
-    def sd(name):
-        obj = getattr(trainer, name, None)
-        return obj.state_dict() if obj else None
 
-    ckpt = {
-        "epoch": int(epoch),
-        "model_state": model_state,
-        "optim_state": sd("optimizer"),
-        "scheduler_state": sd("scheduler"),
-        "scaler_state": sd("scaler"),
-        "trainer_backbone_frozen": getattr(trainer, "_backbone_frozen", False),
-        "latest_val_stats": getattr(trainer, "latest_val_stats", {}),
-        "cfg": getattr(trainer, "cfg", None),
-    }
-    ckpt["model"] = ckpt["model_state"]
-    ckpt["opt"] = ckpt["optim_state"]
-    ckpt["sched"] = ckpt["scheduler_state"]
-    torch.save(ckpt, os.path.join(out_dir, "last.ckpt"))
-    if is_best:
-        torch.save(ckpt, os.path.join(out_dir, "best.ckpt"))
+def read(path: str, map_location=None, weights_only: bool = True):
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"Checkpoint not found: {path}")
+    if map_location is None:
+        map_location = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cpu"
+    return torch.load(path, map_location=map_location, weights_only=weights_only)
 
 
 def load_checkpoint(path: str, model: torch.nn.Module, optimizer=None, scheduler=None, trainer=None,
                     map_location=None, strict=False, weights_only=True):
-    log.info("Attempting to load checkpoint from: %s", path)
-    if not os.path.exists(path):
-        raise FileNotFoundError(f"Checkpoint not found: {path}")
-    if map_location is None:
-        map_location = "cpu" if not torch.cuda.is_available() else f"cuda:{torch.cuda.current_device()}"
-    ckpt = torch.load(path, map_location=map_location, weights_only=weights_only)
-
-    model_state, _ = _pick(ckpt, keys=["model_state", "model", "state_dict"])
-    optim_state, _ = _pick(ckpt, keys=["optim_state", "opt", "optimizer"])
-    sched_state, _ = _pick(ckpt, keys=["scheduler_state", "sched", "scheduler"])
-    scaler_state, _ = _pick(ckpt, keys=["scaler_state", "scaler"])
-
-    if model_state is not None:
-        curr_keys = set(model.state_dict().keys())
-        loaded_keys = list(model_state.keys())
-        new_state = model_state
-        if any(k.startswith("module.") for k in loaded_keys) and not any(k.startswith("module.") for k in curr_keys):
-            new_state = {k.replace("module.", ""): v for k, v in model_state.items()}
-        elif any(k.startswith("module.") for k in curr_keys) and not any(k.startswith("module.") for k in loaded_keys):
-            new_state = {"module." + k: v for k, v in model_state.items()}
-        model.load_state_dict(new_state, strict=strict)
-
-    if optimizer and optim_state:
-        optimizer.load_state_dict(optim_state)
-    if scheduler and sched_state:
-        scheduler.load_state_dict(sched_state)
-    if trainer and scaler_state and hasattr(trainer, "scaler"):
-        trainer.scaler.load_state_dict(scaler_state)
-
-    epoch = ckpt.get("epoch") or ckpt.get("epo")
-    start_epoch = int(epoch) + 1 if epoch is not None else 1
-    return {"start_epoch": start_epoch, "raw": ckpt}
+    """Restore model (+ optimizer / scheduler / trainer.scaler when given).  Returns {"start_epoch", "raw"} like the
+    reference: training resumes at the epoch after the stored one, or at 1 when none is stored."""
+    log.info("loading checkpoint %s", path)
+    ckpt = read(path, map_location, weights_only)
+    state = section(ckpt, "model")
+    if state is not None:
+        model.load_state_dict(match_prefix(state, model.state_dict().keys()), strict=strict)
+    receivers = (("optimizer", optimizer), ("scheduler", scheduler),
+                 ("scaler", getattr(trainer, "scaler", None) if trainer else None))
+    for name, obj in receivers:
+        stored = section(ckpt, name)
+        if obj and stored:
+            obj.load_state_dict(stored)
+    epoch = next((ckpt[k] for k in EPOCH_KEYS if isinstance(ckpt, Mapping) and ckpt.get(k)), None)
+    return {"start_epoch": 1 if epoch is None else int(epoch) + 1, "raw": ckpt}

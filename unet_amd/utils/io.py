@@ -1,46 +1,24 @@
-"""/root/reference/utils/io.py:4-45 with the same names: timestamp, ensure_dir, save_config, save_state and the
-inference-side load_checkpoint (state_dict under `state_dict` / `model` / `model_state_dict` or bare; `module.`
-prefix stripped; strict=False)."""
-import os
-from datetime import datetime
+"""Inference-side checkpoint loading with the call shape of /root/reference/utils/io.py:19-45
+(`load_checkpoint(path, model, device)` -> model), which infer.py and eval_ensemble.py use.  The file may be a training
+checkpoint (any alias of the model section, see checkpoint_utils.FIELDS) or a bare state_dict; a `module.` prefix is
+fixed up; loading is non-strict and reports what did not line up.  The reference's other helpers in that file
+(timestamp / ensure_dir / save_config / save_state) are run-directory housekeeping outside the hot path (SURVEY 2, row
+13) and are not provided."""
+import logging
 
-import torch
-import yaml
+from . import checkpoint_utils as cu
 
-
-def timestamp():
-    return datetime.now().strftime("%Y%m%d-%H%M%S")
-
-
-def ensure_dir(p):
-    os.makedirs(p, exist_ok=True)
-
-
-def save_config(cfg, out_dir):
-    ensure_dir(out_dir)
-    with open(os.path.join(out_dir, "config.yaml"), "w") as f:
-        yaml.safe_dump(cfg, f)
-
-
-def save_state(path, state):
-    torch.save(state, path)
+log = logging.getLogger("unet_amd.checkpoint")
 
 
 def load_checkpoint(path, model, device="cuda", weights_only=True):
-    ckpt = torch.load(path, map_location=device, weights_only=weights_only)
-    if "state_dict" in ckpt:
-        state_dict = ckpt["state_dict"]
-    elif "model" in ckpt:
-        state_dict = ckpt["model"]
-    elif "model_state_dict" in ckpt:
-        state_dict = ckpt["model_state_dict"]
-    else:
-        state_dict = ckpt
-    new_state_dict = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-    missing, unexpected = model.load_state_dict(new_state_dict, strict=False)
-    print(f"Loaded checkpoint from {path}")
-    if missing:
-        print("Missing keys:", missing)
-    if unexpected:
-        print("Unexpected keys:", unexpected)
+    ckpt = cu.read(path, map_location=device, weights_only=weights_only)
+    state = cu.section(ckpt, "model")
+    if state is None:
+        state = ckpt                                   # a bare state_dict
+    result = model.load_state_dict(cu.match_prefix(state, model.state_dict().keys()), strict=False)
+    log.info("loaded %s", path)
+    for label, keys in (("missing", result.missing_keys), ("unexpected", result.unexpected_keys)):
+        if keys:
+            log.warning("%s keys: %s", label, keys)
     return model
