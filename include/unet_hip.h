@@ -34,8 +34,11 @@ const char* unet_last_error(void);
  * and its dgrad (kh=2,kw=1,stride_h=2 on the [N,2H,W,2C] view of the output gradient).
  * w: packed [kh*kw][Cout][Cin] (unet_pack_weights).  bias/stats may be NULL.  stats receives
  * unet_conv_tiles() rows of [Cout][2] = partial (sum, sum of squares) of the fp32 outputs; only the
- * sum over the rows is defined (a row may carry several tiles' sums and others zeros). */
-int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout);
+ * sum over the rows is defined (a row may carry several tiles' sums and others zeros; the row count depends on the
+ * kernel that serves the launch, hence the launch's Cin / Cout / flags / csplit in unet_conv_tiles) -- unless flags
+ * bit 2 asks for per-tile rows grouped per image ([N][tiles per image], what unet_gn_finalize reads). */
+int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout,
+                    int Cin, int Cout, int flags, int csplit);
 int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                   const void* x, const void* w, const float* bias, void* y, float* stats,
                   int N, int Hin, int Win, int Cin, int ldx, int xoff,
@@ -43,7 +46,8 @@ int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
                   int pad_h, int pad_w,
                   void* y2, int ldy2, int yoff2, int csplit, int flags, void* stream);
 /* flags bit 0: y += conv(x) (the RepUNet branch dgrads sum into one input gradient); bit 1: ReLU
- * on the stored result (deployed RepUNet: conv + bias + ReLU, models/reparm_unet.py:162-167).
+ * on the stored result (deployed RepUNet: conv + bias + ReLU, models/reparm_unet.py:162-167); bit 2: statistics rows
+ * per tile and per image (GroupNorm, models/reparm_unet.py:17-25).
  * csplit > 0: output channels >= csplit are written to y2 (channel co - csplit) instead of y; the
  * dgrad of the first decoder conv uses it to hand the skip half and the upsampled half of the
  * concat gradient to two dense buffers (torch.cat backward, models/unet.py:59). */

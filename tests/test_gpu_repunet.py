@@ -199,3 +199,29 @@ def test_repunet_batchnorm_variant_eval_backward_vs_oracle(dev):
     assert relmax(out.detach().cpu(), ref.detach()) < 1e-4
     for k, p in m.named_parameters():
         assert relmax(p.grad.cpu(), st[k].grad) < 3e-4, (k, relmax(p.grad.cpu(), st[k].grad))
+
+
+def test_repunet_groupnorm_64_channels_bf16_stats_stay_per_image(dev):
+    """GroupNorm needs PER-IMAGE statistics rows from the conv epilogue.  At 64 channels and whole 16x32 tiles the bf16
+    3x3 kernel would otherwise use its deferred statistics (one row per workgroup, summed over tiles of several images);
+    the engine asks for per-tile rows (conv flags bit 2).  Images of very different scale make any mixing visible."""
+    from oracle import unet_ref
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(11)
+    m = REGISTRY["reparam_unet"](in_channels=1, n_classes=2, features=[64], kernel_sizes=[3])
+    st = {k: v.clone() for k, v in m.state_dict().items()}
+    gen = torch.Generator().manual_seed(12)
+    x = torch.rand(3, 1, 32, 32, generator=gen)
+    x[1] *= 5.0
+    x[2] = x[2] * 0.2 + 0.7
+    with torch.no_grad():
+        ref = unet_ref.repunet_forward(x, st, [3], norm="group", train=True)
+    m = m.to(dev).train()
+    with torch.no_grad():
+        out32 = m(x.to(dev))
+        with torch.amp.autocast(device_type="cuda", dtype=torch.bfloat16):
+            out16 = m(x.to(dev))
+    assert relmax(out32.cpu(), ref) < 1e-4
+    for n in range(3):              # per image: a wrong statistic of one image must not hide behind the others
+        e = float((out16[n].float().cpu() - ref[n]).norm() / ref[n].norm())
+        assert e < 3e-2, (n, e)

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         return m;
     };
     // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
-    auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot) {
+    auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot, bool bias_only) {
         int cnt = 0;
         if (!producer) return cnt;
         if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) {
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             lds_dma16_buf(make_rsrc(a.bias + t.cb * BCO, (unsigned)nb), (unsigned)lane * 16u,
                           __builtin_amdgcn_readfirstlane(sb + C::OFF_BIAS + bslot * 1024));
         }
+        if (bias_only) return cnt;
 #pragma unroll
         for (int i = 0; i < (C::W_PIECES + NPROD - 1) / NPROD; ++i) {
             const int p = wave + NPROD * i;
@@ -229,9 +230,16 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // count right after the stage's last request.  vmcnt retires in order, so "stage X has landed" is
     // "all but (n_issued - mark[X]) of my youngest requests are done".
     int n_issued = 0, w_mark0 = 0, w_mark1 = 0, h_mark0 = 0, h_mark1 = 0;
+    // RESIDENT WEIGHTS: whole-kernel phases (64-channel tiles), two chunks (Cin = 64) and one channel block: the two weight
+    // stages then hold chunk 0 and chunk 1 for good -- every later request would rewrite a stage with the bytes it already
+    // holds -- so after the first two only the tile's bias piece is requested: 72 of a tile's 152 DMA pieces go away
+    // (64->64 @512^2, same box: forward 0.770 -> 0.740 ms, dgrad 0.644 -> 0.604 ms).
+    const bool w_resident = NPH == 1 && nchunks == 2 && nco == 1;
+    int w_pushed = 0;
     auto push_w = [&]() {
         if (!wq_.valid) return;
-        n_issued += issue_w(wq_.t, wq_.c, wq_.ph, wstage_i, wq_.seq);
+        n_issued += issue_w(wq_.t, wq_.c, wq_.ph, wstage_i, wq_.seq, w_resident && w_pushed >= 2);
+        w_pushed += w_pushed < 2;
         if (wstage_i) w_mark1 = n_issued; else w_mark0 = n_issued;
         wstage_i ^= 1;
         if (++wq_.ph == NPH) { wq_.ph = 0; if (++wq_.c == nchunks) next_tile(wq_); }
@@ -567,13 +575,23 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
 }
 
 // stat rows the bf16 3x3 path writes: one per 16x32 pixel tile
-int conv2_tiles(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wout + 31) / 32); }
+int conv2_rows(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wout + 31) / 32); }
 
+// MEASURED AND NOT KEPT (round 2, same-box A/B against this kernel):
+//  * 256-thread workgroups on 8x32-pixel tiles, two per CU, for the HBM-bound 64-channel layers (one workgroup's store
+//    burst under the other's MFMAs): correct, 6-12 % SLOWER (64->64 @512^2 forward 0.86 vs 0.78 ms).  The weights are
+//    re-streamed per tile, so halving the tile doubles the LDS-DMA instructions per MFMA (29 vs 19 per wave and tile);
+//  * output channels permuted in the weight image so that a lane's accumulators are two 8-channel runs of its pixel and
+//    the epilogue stores 2 x 16 bytes per lane straight from registers (no LDS transposition): correct, 0-4 % SLOWER --
+//    64-byte runs per pixel and instruction cost more at the memory side than the whole 128-byte lines of the transposed
+//    form (128-channel dgrad into a 2.1 GB tensor: 1.106 -> 1.147 ms).
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     const int bco = a.Cout > 64 ? 128 : 64;
     const bool gen = (a.Cin & 31) != 0 || (a.Cout % bco) != 0 || (a.Hout & 15) != 0 || (a.Wout & 31) != 0 ||
                      (a.flags & 1) != 0 || (a.csplit & 63) != 0;
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
     if (gen) return launch_conv2<1, true>(a, s);
-    return a.stats != nullptr ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false>(a, s);
+    // deferred statistics put a workgroup's sums (over tiles of several images) into one row: not for flags bit 2
+    // (per-tile rows grouped per image, what GroupNorm's finalize reads)
+    return (a.stats != nullptr && (a.flags & 4) == 0) ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false>(a, s);
 }

@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include "conv_args.h"
+#include <cstdlib>
 
 template <typename T, int KH, int KW, int SH, int TG, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -250,7 +251,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 }
 
 // bf16 3x3 stride-1 path (conv_fwd2.hip)
-int conv2_tiles(int N, int Hout, int Wout);
+int conv2_rows(int N, int Hout, int Wout);
 int dispatch_conv2(const ConvArgs& a, hipStream_t s);
 // bf16 ConvTranspose2d forward / dgrad on whole tiles (conv_t2.hip)
 bool convT2_fwd_ok(const ConvArgs& a);
@@ -283,8 +284,9 @@ static int dispatch_conv(int kh, int kw, int sh, int epi, const ConvArgs& a, hip
 }
 
 // stats_count() tells the caller how many partial rows unet_conv_fwd writes: one per pixel tile.
-extern "C" int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout) {
-    if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_tiles(N, Hout, Wout);
+extern "C" int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout,
+                               int Cin, int Cout, int flags, int csplit) {
+    if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_rows(N, Hout, Wout);
     return N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
 }
 

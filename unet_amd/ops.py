@@ -201,8 +201,10 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, norm_out: Optional[torch.Tens
 def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act, kh: int, kw: int,
              Cin: int, Cout: int, stats: bool = False, stride_h: int = 1, epi: int = 0,
              pad_h: Optional[int] = None, pad_w: Optional[int] = None,
-             y2: Optional[Act] = None, csplit: int = 0, accumulate: bool = False, relu: bool = False):
-    """y = conv(x) (+bias).  Returns the BN partial-stat rows tensor when stats=True.
+             y2: Optional[Act] = None, csplit: int = 0, accumulate: bool = False, relu: bool = False,
+             per_image_stats: bool = False):
+    """y = conv(x) (+bias).  Returns the BN partial-stat rows tensor when stats=True (per_image_stats: one row per
+    pixel tile, grouped per image, as gn_finalize needs; otherwise only the sum over the rows is defined).
     epi=1: 1x1 conv with Cout = 4*C and 2x2 pixel shuffle into y (ConvTranspose2d forward)."""
     x.check(); y.check()
     dt = x.dt
@@ -233,14 +235,15 @@ def conv_fwd(x: Act, wpacked: torch.Tensor, bias: Optional[torch.Tensor], y: Act
         if bias.numel() != nb or bias.dtype != torch.float32:
             raise UNetHipError("conv: bias must be fp32 of length Cout")
     rows = None
+    flags = (1 if accumulate else 0) | (2 if relu else 0) | (4 if per_image_stats else 0)
+    cs = csplit if y2 is not None else 0
     if stats:
-        nrows = lib().unet_conv_tiles(dt, kh, kw, stride_h, epi, x.N, Hout, Wout)
+        nrows = lib().unet_conv_tiles(dt, kh, kw, stride_h, epi, x.N, Hout, Wout, Cin, Cout, flags, cs)
         rows = torch.empty((nrows, Cout, 2), dtype=torch.float32, device=x.buf.device)
     check(lib().unet_conv_fwd(dt, kh, kw, stride_h, epi, _p(x.buf), _p(wpacked), _p(bias), _p(y.buf), _p(rows),
                               x.N, x.H, x.W, Cin, x.ld, x.off, Hout, Wout, Cout, y.ld, y.off, ph, pw,
                               _p(y2.buf) if y2 is not None else None, y2.ld if y2 is not None else 0,
-                              y2.off if y2 is not None else 0, csplit if y2 is not None else 0,
-                              (1 if accumulate else 0) | (2 if relu else 0), _stream()), "conv_fwd")
+                              y2.off if y2 is not None else 0, cs, flags, _stream()), "conv_fwd")
     return rows
 
 

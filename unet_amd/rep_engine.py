@@ -71,7 +71,8 @@ class RepUNetEngine(UNetEngine):
                 if x_f32 is not None:
                     rows = ops.conv_first_fwd(x_f32, w.detach(), None, z, kh, kw, stats=True)
                 else:
-                    rows = ops.conv_fwd(xin, self.packed(wname, w, 0, dt), None, z, kh, kw, Cin, Cout, stats=True)
+                    rows = ops.conv_fwd(xin, self.packed(wname, w, 0, dt), None, z, kh, kw, Cin, Cout, stats=True,
+                                        per_image_stats=self.norm == "group")
                 gamma, beta = P[bnp + ".weight"].detach(), P[bnp + ".bias"].detach()
                 if self.norm == "group":
                     st = ops.gn_finalize(rows, N, H * W, gamma, beta, min(8, Cout), EPS)
