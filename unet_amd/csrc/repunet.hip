@@ -13,41 +13,56 @@
 
 // ---------------------------------------------------------------------------------------------
 // rows [N*rpi][C][2] (per-tile sum / sumsq, tiles never cross images) -> per-(n,c) scale/shift and
-// per-(n,g) mean/invstd.  One workgroup per image.
+// per-(n,g) mean/invstd.  One workgroup per (image, group): its C/groups channels x 256/(C/groups) row lanes walk the
+// image's rows with coalesced 8-byte loads, the partials are added in lane order (deterministic), then the group's
+// statistics and its channels' coefficients are written.  (The first version used one workgroup per IMAGE with a serial
+// row loop per thread: 95 us per call at 1024 rows, 10 % of a RepUNet training step.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ rows, int rpi, int C, int groups, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                           float* __restrict__ scale, float* __restrict__ shift,
                                                           float* __restrict__ mean_out, float* __restrict__ invstd_out) {
-    extern __shared__ double sm_d[];          // [C][2] then [groups][2]
-    const int n = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < rpi; ++r) {
-            const float2 v = *(const float2*)(rows + (((size_t)n * rpi + r) * C + c) * 2);
+    __shared__ double red[256][2];
+    __shared__ double gstat[2];
+    const int g = blockIdx.x, n = blockIdx.y;
+    const int cg = C / groups;                          // channels of this group (<= 256, checked by the launcher)
+    const int RL = 256 / cg;                            // row lanes
+    const int ch = threadIdx.x % cg, rl = threadIdx.x / cg;
+    double s1 = 0.0, s2 = 0.0;
+    if (rl < RL) {
+        const float* col = rows + ((size_t)n * rpi * C + (size_t)g * cg + ch) * 2;
+        int r = rl;
+        for (; r + 3 * RL < rpi; r += 4 * RL) {         // four independent loads in flight
+            const float2 v0 = *(const float2*)(col + (size_t)r * C * 2);
+            const float2 v1 = *(const float2*)(col + (size_t)(r + RL) * C * 2);
+            const float2 v2 = *(const float2*)(col + (size_t)(r + 2 * RL) * C * 2);
+            const float2 v3 = *(const float2*)(col + (size_t)(r + 3 * RL) * C * 2);
+            s1 += (double)v0.x; s2 += (double)v0.y; s1 += (double)v1.x; s2 += (double)v1.y;
+            s1 += (double)v2.x; s2 += (double)v2.y; s1 += (double)v3.x; s2 += (double)v3.y;
+        }
+        for (; r < rpi; r += RL) {
+            const float2 v = *(const float2*)(col + (size_t)r * C * 2);
             s1 += (double)v.x; s2 += (double)v.y;
         }
-        sm_d[c * 2] = s1; sm_d[c * 2 + 1] = s2;
     }
+    red[threadIdx.x][0] = s1; red[threadIdx.x][1] = s2;
     __syncthreads();
-    const int cg = C / groups;
-    double* gs = sm_d + 2 * C;
-    for (int g = threadIdx.x; g < groups; g += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int c = g * cg; c < (g + 1) * cg; ++c) { s1 += sm_d[c * 2]; s2 += sm_d[c * 2 + 1]; }
-        const double m = s1 / count;
-        double var = s2 / count - m * m;
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < RL * cg; ++i) { a += red[i][0]; b += red[i][1]; }
+        const double m = a / count;
+        double var = b / count - m * m;
         if (var < 0.0) var = 0.0;
-        gs[g * 2] = m;
-        gs[g * 2 + 1] = 1.0 / sqrt(var + (double)eps);
+        gstat[0] = m;
+        gstat[1] = 1.0 / sqrt(var + (double)eps);
         mean_out[n * groups + g] = (float)m;
-        invstd_out[n * groups + g] = (float)gs[g * 2 + 1];
+        invstd_out[n * groups + g] = (float)gstat[1];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const int g = c / cg;
-        const float sc = gamma[c] * (float)gs[g * 2 + 1];
+    if (threadIdx.x < cg) {
+        const int c = g * cg + threadIdx.x;
+        const float sc = gamma[c] * (float)gstat[1];
         scale[(size_t)n * C + c] = sc;
-        shift[(size_t)n * C + c] = beta[c] - (float)gs[g * 2] * sc;
+        shift[(size_t)n * C + c] = beta[c] - (float)gstat[0] * sc;
     }
 }
 
@@ -227,9 +242,9 @@ extern "C" int unet_gn_finalize(const float* stat_rows, int N, int rows_per_imag
                                 float* scale /* [N][C] */, float* shift /* [N][C] */, float* mean /* [N][groups] */, float* invstd,
                                 void* stream) {
     UNET_CHECK(N > 0 && rows_per_image > 0 && C > 0 && groups > 0 && C % groups == 0, "gn_finalize: bad shape");
-    const size_t lds = sizeof(double) * (2 * (size_t)C + 2 * groups);
-    UNET_CHECK(lds <= 65536, "gn_finalize: C too large");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, stat_rows, rows_per_image, C, groups,
+    UNET_CHECK(C / groups <= 256, "gn_finalize: at most 256 channels per group (got %d)", C / groups);
+    UNET_CHECK(stat_rows && gamma && beta && scale && shift && mean && invstd, "gn_finalize: null argument");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, N), dim3(256), 0, (hipStream_t)stream, stat_rows, rows_per_image, C, groups,
                        (double)HW * (C / groups), gamma, beta, eps, scale, shift, mean, invstd);
     UNET_LAUNCH_CHECK();
     return 0;
