@@ -70,6 +70,7 @@ int unet_convT_wgrad_reduce(const float* slab, float* dw, int nsplit, int Ci, in
 /* ---- first conv (Cin<=4, fp32 image in) and final 1x1 conv (fp32 NCHW logits out) -----------
  * models/unet.py:30 (in_channels=1) and models/unet.py:39,62. */
 int unet_conv_first_rows(int dtype, int N, int H, int W, int Cout);
+/* z may be NULL for the Cin = 1 3x3 case: statistics rows only (see unet_first_bn_act). */
 int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, const float* w, const float* bias, void* z, float* stats,
                         int N, int H, int W, int Cin, int Cout, void* stream);
 int unet_conv_first_wgrad(int dtype, int kh, int kw, const void* dz, const float* x, float* dw,
@@ -79,6 +80,33 @@ int unet_conv_out_fwd(int dtype, const void* x, int ldx, int xoff, const float* 
 int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, int xoff, const float* w,
                       void* dx, float* dw, float* db, long long M, long long HW, int C, int K,
                       double* acc_ws, void* stream);
+
+/* ---- the two ends of the U-Net fused into their BatchNorm passes (edge_fused.hip) --------------
+ * First layer, in_channels = 1, 3x3 (models/unet.py:30 + :11-12).  Forward: unet_conv_first_fwd with z = NULL writes only the
+ * statistics rows; after unet_bn_finalize, unet_first_bn_act computes y = act(scale*conv(x)+shift) in one pass: the pre-norm
+ * tensor is never stored.  Backward: unet_first_bn_relu_bwd = unet_bn_relu_bwd with that tensor recomputed from x, plus the
+ * conv's weight gradient dw (Cout,1,3,3) accumulated from the dz it holds in registers (dz is not stored: the first conv has
+ * no input gradient).  relu bits as unet_bn_relu_bwd.  acc_ws: 12*Cout doubles. */
+int unet_first_bn_act(int dtype, int relu, const float* x, const float* w, const float* bias,
+                      const float* scale, const float* shift, void* y, int ldy, int yoff,
+                      int N, int H, int W, int Cout, void* stream);
+int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff,
+                           const float* x, const float* w, const float* bias,
+                           const float* scale, const float* shift, const float* mean, const float* invstd,
+                           float* dgamma, float* dbeta, float* dbias, float* dw,
+                           float* c1c2_ws, double* acc_ws, int N, int H, int W, int Cout, void* stream);
+/* Last layer (models/unet.py:14-15 of the last DoubleConv + final_conv :39,62), n_classes <= 4.  Forward:
+ * logits = W act(scale*z+shift) + b in one pass (y optional, may be NULL).  Backward: unet_bn_relu_bwd with its incoming
+ * gradient recomputed per element as W^T dlogits, and final_conv's dw (K,C) / db (K) accumulated from the recomputed
+ * activation.  acc_ws: 3*C + K*C + K doubles. */
+int unet_affine_act_out(int dtype, int relu, const void* z, int ldz, int zoff, const float* scale, const float* shift,
+                        const float* w, const float* bias, float* logits, void* y, int ldy, int yoff,
+                        long long M, long long HW, int C, int K, void* stream);
+int unet_bn_relu_bwd_out(int dtype, int relu, const float* dlogits, const float* w, int K, long long HW,
+                         const void* z, int ldz, int zoff, void* dz, int ldo, int ooff,
+                         const float* scale, const float* shift, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, float* dbias, float* dw, float* db,
+                         float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
 
 /* fp32 master weights -> packed compute-dtype images.  mode 0 conv fwd, 1 conv dgrad (flipped,
  * transposed), 2 convT fwd, 3 convT dgrad.  O,I = dims 0,1 of the source tensor. */

@@ -159,7 +159,17 @@ def _hip_decisions(engine):
         pool[f"pool{i}"] = ops.pool_indices_int64(sv.codes[i], sv.cats[i].shape[2]).cpu()
     post["bottleneck.b"] = _nchw(sv.up_in[0])
     for j in range(L):
-        post[f"ups.{2 * j + 1}.b"] = _nchw(sv.up_in[j + 1]) if j + 1 < L else _nchw(sv.last)
+        if j + 1 < L:
+            post[f"ups.{2 * j + 1}.b"] = _nchw(sv.up_in[j + 1])
+        elif sv.last is not None:
+            post[f"ups.{2 * j + 1}.b"] = _nchw(sv.last)
+        else:
+            # fused output head: the last activation is never stored; the backward passes decide the ReLU by
+            # fmaf(z, scale, shift) > 0, which is exactly what the stand-alone BN+ReLU kernel computes
+            r2 = sv.blocks[f"ups.{2 * j + 1}"][1]
+            y = ops.dense(r2.z.N, r2.z.H, r2.z.W, r2.z.C, r2.z.dt, r2.z.buf.device)
+            ops.affine_act(r2.z, y, r2.st, relu=True)
+            post[f"ups.{2 * j + 1}.b"] = _nchw(y)
     return post, pool
 
 

@@ -6,8 +6,9 @@
 //                 bandwidth-bound on its INPUT
 //   pack        : fp32 OIHW / (Cin,Cout,2,2) master weights -> [tap][Cout][Cin] compute-dtype images
 #include "common.h"
+#include "bn_shared.h"
 
-#define MAX_GRID 2048
+
 
 // ------------------------------------------------------------------------------------------------
 // first conv forward: x fp32 [N,H,W,Cin], w fp32 OIHW, z T [N,H,W,Cout] + BN partial rows [grid][Cout][2]
@@ -143,16 +144,6 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const T* __restri
 // the thread's weights / weight-gradient partials in registers and walk DOWN a column strip with a sliding
 // 3x3 window, so a pixel costs 3 input loads instead of 9 and no LDS traffic.  Thread = (pixel lane, group
 // of EPV output channels); a workgroup covers PL = 256/(Cout/EPV) adjacent columns x FIRST_R rows per tile.
-constexpr int FIRST_R = 16;
-
-__device__ __forceinline__ void first_row3(const float* __restrict__ xi, int hh, int wq, int H, int W, float* r) {
-    const bool rowok = (unsigned)hh < (unsigned)H;
-    const float* xr = xi + (long long)hh * W;
-    r[0] = (rowok && wq >= 1) ? xr[wq - 1] : 0.f;
-    r[1] = rowok ? xr[wq] : 0.f;
-    r[2] = (rowok && wq + 1 < W) ? xr[wq + 1] : 0.f;
-}
-
 // 4 waves per SIMD (128 VGPRs, 6 spilled outside the row loop) instead of the 3 the 136 registers of the natural allocation
 // allow: 428 -> 358 us at 32 x 512^2 x 64 (the kernel is latency-bound: one dependent 3-row load chain per thread).
 template <typename T>
@@ -199,7 +190,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 acc[e] = v;
                 s1[e] += v; s2[e] = fmaf(v, v, s2[e]);
             }
-            *(uint4*)(zi + ((long long)h * W + wq) * Cout + cg * EPV) = Vec16<T>::pack(acc);
+            if (z != nullptr) *(uint4*)(zi + ((long long)h * W + wq) * Cout + cg * EPV) = Vec16<T>::pack(acc);      // NULL: statistics only
 #pragma unroll
             for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; rc[k] = rn[k]; }
         }
@@ -505,6 +496,9 @@ extern "C" int unet_conv_first_fwd(int dtype, int kh, int kw, const float* x, co
     UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
     UNET_CHECK(Cin >= 1 && Cin <= 4, "first-conv kernel serves Cin <= 4 (got %d)", Cin);
     UNET_CHECK(Cout % 8 == 0 && Cout > 0, "Cout must be a multiple of 8");
+    UNET_CHECK(x != nullptr && w != nullptr, "first conv: null argument");
+    UNET_CHECK(z != nullptr || (kh == 3 && kw == 3 && Cin == 1 && stats != nullptr),
+               "first conv: z may be NULL (statistics only) for the Cin = 1 3x3 kernel with a statistics buffer");
     const int rows = unet_conv_first_rows(dtype, N, H, W, Cout);
     UNET_CHECK(rows > 0, "Cout=%d too wide for the first-conv kernel", Cout);
     const int epv = dtype == UNET_BF16 ? 8 : 4;

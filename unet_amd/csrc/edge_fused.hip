@@ -1,0 +1,508 @@
+// The two ENDS of the U-Net fused into their BatchNorm passes (gfx950).  Both layers have next to no arithmetic -- the
+// first conv is 9 MACs per output (in_channels = 1), the final conv 2 MACs per input -- so their tensors are cheaper to
+// recompute inside the neighbouring bandwidth-bound pass than to store and read back:
+//
+//   first DoubleConv conv (models/unet.py:30 with in_channels = 1, then BatchNorm2d + ReLU, :11-12)
+//     forward : statistics-only conv pass (unet_conv_first_fwd with z = NULL), then ONE pass x -> y = relu(bn(conv(x)));
+//               the pre-norm tensor z0 (1.07 GB at 32 x 512^2 x 64 bf16) is never written or read;
+//     backward: BN backward with z0 recomputed from x in both passes, and the conv's weight gradient accumulated in
+//               the second pass from the dz it has in registers: dz0 is never written either (the first conv has no
+//               input gradient to produce).  6.4 GB -> 2.2 GB of traffic for this layer's backward.
+//   last DoubleConv BatchNorm + ReLU followed by final_conv 1x1 (models/unet.py:14-15,39,62)
+//     forward : ONE pass z -> logits = W relu(bn(z)) + b; the last activation y is never written or read;
+//     backward: BN backward whose incoming gradient dy = W^T dlogits is recomputed per element from the 2-8 logit
+//               gradients of the pixel (8 B/pixel instead of 128), with final_conv's dW / db accumulated in the first
+//               pass from the recomputed y: neither y nor dy exists in memory.  14 -> 6.3 B/element.
+//
+// Numerics are those of the unfused kernel sequence: every tensor that sequence stores in the compute dtype T (z0, y,
+// dy, dz0) is rounded to T here at the same point (round_to<T>), so the two paths agree to the last bit except for the
+// order of fp64 atomic adds.
+#include "bn_shared.h"
+
+// =================================================================================================
+// first layer
+// =================================================================================================
+
+// y = act(scale * round_T(conv3x3(x) + bias) + shift), Cin = 1; same column-strip walk as conv_first1_fwd_kernel
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void first1_bn_act_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            T* __restrict__ y, int ldy, int yoff, int H, int W, int Cout) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = Cout / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    if (pl >= PL) return;
+    float wr[9][EPV], b[EPV], sc[EPV], sh[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        const int c = cg * EPV + e;
+        b[e] = bias != nullptr ? bias[c] : 0.f;
+        sc[e] = scale[c]; sh[e] = shift[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t][e] = w[c * 9 + t];
+    }
+    const int tiles_w = (W + PL - 1) / PL, tiles_h = (H + FIRST_R - 1) / FIRST_R;
+    const float* xi = x + (long long)blockIdx.y * H * W;
+    T* yi = y + (long long)blockIdx.y * H * W * ldy + yoff;
+    for (int tile = blockIdx.x; tile < tiles_w * tiles_h; tile += gridDim.x) {
+        const int th = tile / tiles_w, tw = tile - th * tiles_w;
+        const int h0 = th * FIRST_R, wq = tw * PL + pl;
+        if (wq >= W) continue;
+        const int h1 = min(h0 + FIRST_R, H);
+        float ra[3], rb[3], rc[3], rn[3];
+        first_row3(xi, h0 - 1, wq, H, W, ra);
+        first_row3(xi, h0, wq, H, W, rb);
+        first_row3(xi, h0 + 1, wq, H, W, rc);
+        for (int h = h0; h < h1; ++h) {
+            first_row3(xi, h + 2, wq, H, W, rn);
+            float o[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float v = b[e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    v = fmaf(ra[k], wr[k][e], v);
+                    v = fmaf(rb[k], wr[3 + k][e], v);
+                    v = fmaf(rc[k], wr[6 + k][e], v);
+                }
+                v = fmaf(round_to<T>(v), sc[e], sh[e]);
+                o[e] = RELU ? fmaxf(v, 0.f) : v;
+            }
+            *(uint4*)(yi + ((long long)h * W + wq) * ldy + cg * EPV) = Vec16<T>::pack(o);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; rc[k] = rn[k]; }
+        }
+    }
+}
+
+// BN+ReLU backward of the first layer with z0 = round_T(conv(x)) recomputed.
+//   PASS 1: S1 = sum dy', S2 = sum dy' * xhat                      -> acc[C][2]
+//   PASS 2: dz = round_T(scale * (dy' - c1 - xhat*c2)); sum dz     -> dbias acc[C]
+//           dW[co][tap] = sum_p dz[p][co] * x[p + tap]             -> wacc[C][9]   (dz is not stored)
+template <typename T, bool RELU, int PASS>
+__global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict__ dy, int ldd, int doff,
+                                                            const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ c1, const float* __restrict__ c2,
+                                                            int N, int H, int W, int Cout,
+                                                            double* __restrict__ acc, double* __restrict__ wacc) {
+    constexpr int EPV = TT<T>::EPV;
+    ChanMap m; m.init<T>(Cout);
+    float part[2 * EPV];
+#pragma unroll
+    for (int i = 0; i < 2 * EPV; ++i) part[i] = 0.f;
+    float pw[PASS == 2 ? 9 : 1][EPV];
+#pragma unroll
+    for (int t = 0; t < (PASS == 2 ? 9 : 1); ++t)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) pw[t][e] = 0.f;
+    if (m.active) {
+        float wr[9][EPV], b[EPV], sc[EPV], sh[EPV], mu[EPV], is[EPV], k1[EPV], k2[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = m.cg * EPV + e;
+            b[e] = bias != nullptr ? bias[c] : 0.f;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+            k1[e] = PASS == 2 ? c1[c] : 0.f; k2[e] = PASS == 2 ? c2[c] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wr[t][e] = w[c * 9 + t];
+        }
+        const int tiles_w = (W + m.PL - 1) / m.PL, tiles_h = (H + FIRST_R - 1) / FIRST_R;
+        const int per_img = tiles_w * tiles_h;
+        for (long long tile = blockIdx.x; tile < (long long)per_img * N; tile += gridDim.x) {
+            const int n = (int)(tile / per_img), tt = (int)(tile - (long long)n * per_img);
+            const int th = tt / tiles_w, tw = tt - th * tiles_w;
+            const int h0 = th * FIRST_R, wq = tw * m.PL + m.pl;
+            if (wq >= W) continue;
+            const int h1 = min(h0 + FIRST_R, H);
+            const float* xi = x + (long long)n * H * W;
+            const T* di = dy + (long long)n * H * W * ldd + doff + m.cg * EPV;
+            float ra[3], rb[3], rc[3], rn[3];
+            first_row3(xi, h0 - 1, wq, H, W, ra);
+            first_row3(xi, h0, wq, H, W, rb);
+            first_row3(xi, h0 + 1, wq, H, W, rc);
+            uint4 gq = *(const uint4*)(di + ((long long)h0 * W + wq) * ldd);
+            for (int h = h0; h < h1; ++h) {
+                first_row3(xi, h + 2, wq, H, W, rn);          // next row's inputs and gradient in flight under the FMAs
+                const uint4 gn = h + 1 < h1 ? *(const uint4*)(di + ((long long)(h + 1) * W + wq) * ldd) : gq;
+                float fd[EPV];
+                Vec16<T>::unpack(gq, fd);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float v = b[e];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        v = fmaf(ra[k], wr[k][e], v);
+                        v = fmaf(rb[k], wr[3 + k][e], v);
+                        v = fmaf(rc[k], wr[6 + k][e], v);
+                    }
+                    const float z = round_to<T>(v);
+                    const float d = (!RELU || fmaf(z, sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                    const float xh = (z - mu[e]) * is[e];
+                    if constexpr (PASS == 1) {
+                        part[e] += d;
+                        part[EPV + e] += d * xh;
+                    } else {
+                        const float dz = round_to<T>(sc[e] * (d - k1[e] - xh * k2[e]));
+                        part[e] += dz;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            pw[k][e] = fmaf(dz, ra[k], pw[k][e]);
+                            pw[3 + k][e] = fmaf(dz, rb[k], pw[3 + k][e]);
+                            pw[6 + k][e] = fmaf(dz, rc[k], pw[6 + k][e]);
+                        }
+                    }
+                }
+                gq = gn;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; rc[k] = rn[k]; }
+            }
+        }
+    }
+    if constexpr (PASS == 1) {
+        block_reduce_to_acc<2 * EPV>(m, part, EPV, Cout, acc, 2);
+    } else {
+        float p1[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) p1[e] = part[e];
+        block_reduce_to_acc<EPV>(m, p1, EPV, Cout, acc, 1);
+        // weight-gradient partials, one tap at a time through the same reduction (acc row stride 9: wacc[c*9 + t])
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            __syncthreads();
+            float pt[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) pt[e] = pw[t][e];
+            block_reduce_to_acc<EPV>(m, pt, EPV, Cout, wacc + t, 9);
+        }
+    }
+}
+
+static __global__ void first1_store_kernel(const double* __restrict__ dbacc, const double* __restrict__ wacc, int C,
+                                           float* __restrict__ dbias, float* __restrict__ dw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C && dbias != nullptr) dbias[i] = (float)dbacc[i];
+    if (i < C * 9) dw[i] = (float)wacc[i];
+}
+
+// =================================================================================================
+// last layer
+// =================================================================================================
+
+// logits[n][k][hw] = bias[k] + sum_c w[k][c] * round_T(act(z*scale + shift)); y (optional) receives the activation.
+// LP lanes (a power of two >= C/EPV) cooperate on one pixel.
+template <typename T, int K, bool RELU>
+__global__ __launch_bounds__(256) void affine_act_out_kernel(const T* __restrict__ z, int ldz, int zoff,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ logits, T* __restrict__ y, int ldy, int yoff,
+                                                             long long M, long long HW, int C, int LP) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV;
+    const int sub = threadIdx.x & (LP - 1);
+    const int ppb = 256 / LP;
+    const int pslot = threadIdx.x / LP;
+    float wr[K][EPV], sc[EPV], sh[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        sc[e] = sub < G ? scale[sub * EPV + e] : 0.f;
+        sh[e] = sub < G ? shift[sub * EPV + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[k][e] = sub < G ? w[k * C + sub * EPV + e] : 0.f;
+    }
+    float bk[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) bk[k] = bias != nullptr ? bias[k] : 0.f;
+    // every lane of a wave runs the same trip count so the shuffles below see all lanes
+    const long long iters = (M + (long long)gridDim.x * ppb - 1) / ((long long)gridDim.x * ppb);
+    for (long long it = 0; it < iters; ++it) {
+        const long long p = (it * gridDim.x + blockIdx.x) * ppb + pslot;
+        float f[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) f[e] = 0.f;
+        if (p < M && sub < G) {
+            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + sub * EPV), f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float v = fmaf(f[e], sc[e], sh[e]);
+                f[e] = RELU ? fmaxf(v, 0.f) : v;
+            }
+            const uint4 o = Vec16<T>::pack(f);
+            if (y != nullptr) *(uint4*)(y + p * ldy + yoff + sub * EPV) = o;
+            Vec16<T>::unpack(o, f);                   // the 1x1 conv sees what a stored activation would hold
+        }
+        float d[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) s = fmaf(f[e], wr[k][e], s);
+            for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o);
+            d[k] = s + bk[k];
+        }
+        if (p < M && sub == 0) {
+            const long long n = p / HW, hw = p - n * HW;
+#pragma unroll
+            for (int k = 0; k < K; ++k) logits[(n * K + k) * HW + hw] = d[k];
+        }
+    }
+}
+
+// BN+ReLU backward of the last DoubleConv layer with dy[p][c] = round_T(sum_k dlogits[n][k][hw] * w[k][c]).
+//   PASS 1: S1, S2 -> acc[C][2];  dW[k][c] = sum_p dl[k][p] * y[p][c] -> oacc[k*C + c];  db[k] = sum_p dl[k][p] -> oacc[K*C + k]
+//   PASS 2: dz = scale * (dy' - c1 - xhat*c2) stored; sum of the stored dz -> dbias acc[C]
+template <typename T, int K, bool RELU, int PASS>
+__global__ __launch_bounds__(256) void bn_bwd_out_kernel(const float* __restrict__ dl, const float* __restrict__ w,
+                                                         const T* __restrict__ z, int ldz, int zoff,
+                                                         T* __restrict__ dz, int ldo, int ooff,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ c1, const float* __restrict__ c2,
+                                                         long long M, long long HW, int C,
+                                                         double* __restrict__ acc, double* __restrict__ oacc) {
+    constexpr int EPV = TT<T>::EPV;
+    constexpr int KW_ = PASS == 1 ? K : 1;
+    extern __shared__ float red_lds[];
+    ChanMap m; m.init<T>(C);
+    float part[2 * EPV], pw[KW_][EPV], pb[KW_];
+#pragma unroll
+    for (int i = 0; i < 2 * EPV; ++i) part[i] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KW_; ++k) {
+        pb[k] = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) pw[k][e] = 0.f;
+    }
+    if (m.active) {
+        float wr[K][EPV], sc[EPV], sh[EPV], mu[EPV], is[EPV], k1[EPV], k2[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const int c = m.cg * EPV + e;
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+            k1[e] = PASS == 2 ? c1[c] : 0.f; k2[e] = PASS == 2 ? c2[c] : 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) wr[k][e] = w[k * C + c];
+        }
+        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
+            const long long n = p / HW, hw = p - n * HW;
+            float fz[EPV], g[K];
+            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
+#pragma unroll
+            for (int k = 0; k < K; ++k) g[k] = dl[(n * K + k) * HW + hw];
+            float o[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float dyv = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) dyv = fmaf(g[k], wr[k][e], dyv);
+                dyv = round_to<T>(dyv);
+                const float a = fmaf(fz[e], sc[e], sh[e]);
+                const float d = (!RELU || a > 0.f) ? dyv : 0.f;
+                const float xh = (fz[e] - mu[e]) * is[e];
+                if constexpr (PASS == 1) {
+                    part[e] += d;
+                    part[EPV + e] += d * xh;
+                    const float yv = round_to<T>(RELU ? fmaxf(a, 0.f) : a);
+#pragma unroll
+                    for (int k = 0; k < K; ++k) pw[k][e] = fmaf(g[k], yv, pw[k][e]);
+                } else {
+                    o[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+                }
+            }
+            if constexpr (PASS == 1) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) pb[k] += g[k];
+            } else {
+                const uint4 ov = Vec16<T>::pack(o);
+                *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = ov;
+                float fr[EPV];
+                Vec16<T>::unpack(ov, fr);              // sum what the consumers of dz will actually read
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+            }
+        }
+    }
+    if constexpr (PASS == 1) {
+        block_reduce_to_acc<2 * EPV>(m, part, EPV, C, acc, 2);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            __syncthreads();
+            float pt[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) pt[e] = pw[k][e];
+            block_reduce_to_acc<EPV>(m, pt, EPV, C, oacc + (size_t)k * C, 1);
+        }
+        // db: every channel group of a pixel lane carries the same copy; take the cg == 0 threads'
+        __syncthreads();
+        if (m.active && m.cg == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) red_lds[m.pl * K + k] = pb[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < K) {
+            float s = 0.f;
+            for (int p = 0; p < m.PL; ++p) s += red_lds[p * K + threadIdx.x];
+            atomicAdd(&oacc[(size_t)K * C + threadIdx.x], (double)s);
+        }
+    } else {
+        float p1[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) p1[e] = part[e];
+        block_reduce_to_acc<EPV>(m, p1, EPV, C, acc, 1);
+    }
+}
+
+static __global__ void out_store_kernel(const double* __restrict__ oacc, int n, float* __restrict__ dw, int ndw, float* __restrict__ db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ndw) dw[i] = (float)oacc[i];
+    else if (i < n) db[i - ndw] = (float)oacc[i];
+}
+
+// =================================================================================================
+static inline int ef_grid(long long M, int PL) {
+    long long g = (M + PL - 1) / PL;
+    if (g > MAX_GRID) g = MAX_GRID;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static inline int ef_check(int dtype, int C, const char* what) {
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    if (dtype != UNET_F32 && dtype != UNET_BF16) { unet_set_error("%s: bad dtype %d", what, dtype); return -1; }
+    if (C <= 0 || C % 8 != 0 || C / epv > 256) { unet_set_error("%s: C=%d must be a multiple of 8 and at most %d", what, C, 256 * epv); return -1; }
+    return 0;
+}
+static int first_gx2(int dtype, int N, int H, int W, int Cout) {
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    const int G = Cout / epv;
+    int cap = MAX_GRID / N; if (cap < 1) cap = 1;
+    long long g = ((long long)H * W + 256 / G - 1) / (256 / G);
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+extern "C" int unet_first_bn_act(int dtype, int relu, const float* x, const float* w, const float* bias,
+                                 const float* scale, const float* shift, void* y, int ldy, int yoff,
+                                 int N, int H, int W, int Cout, void* stream) {
+    if (ef_check(dtype, Cout, "first_bn_act")) return -1;
+    UNET_CHECK(x && w && scale && shift && y, "first_bn_act: null argument");
+    UNET_CHECK(N > 0 && H > 0 && W > 0 && ldy % 8 == 0 && yoff % 8 == 0 && yoff + Cout <= ldy, "first_bn_act: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(first_gx2(dtype, N, H, W, Cout), N);
+#define LA(T, R) hipLaunchKernelGGL((first1_bn_act_kernel<T, R>), grid, dim3(256), 0, s, x, w, bias, scale, shift, (T*)y, ldy, yoff, H, W, Cout)
+    if (dtype == UNET_BF16) { if (relu & 1) LA(__bf16, true); else LA(__bf16, false); }
+    else { if (relu & 1) LA(float, true); else LA(float, false); }
+#undef LA
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff,
+                                      const float* x, const float* w, const float* bias,
+                                      const float* scale, const float* shift, const float* mean, const float* invstd,
+                                      float* dgamma, float* dbeta, float* dbias /* nullable */, float* dw /* [Cout][1][3][3] */,
+                                      float* c1c2_ws /* 2*Cout floats */, double* acc_ws /* 12*Cout doubles */,
+                                      int N, int H, int W, int Cout, void* stream) {
+    if (ef_check(dtype, Cout, "first_bn_relu_bwd")) return -1;
+    UNET_CHECK(dy && x && w && scale && shift && mean && invstd && dgamma && dbeta && dw && c1c2_ws && acc_ws, "first_bn_relu_bwd: null argument");
+    UNET_CHECK(N > 0 && H > 0 && W > 0 && ldd % 8 == 0 && doff % 8 == 0 && doff + Cout <= ldd, "first_bn_relu_bwd: bad shape");
+    const int frozen = (relu >> 1) & 1;
+    relu &= 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, G = Cout / epv;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 12 * Cout, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    double* dbacc = acc_ws + 2 * Cout;
+    double* wacc = acc_ws + 3 * Cout;
+    float* c1 = c1c2_ws; float* c2 = c1c2_ws + Cout;
+    const long long tiles = (long long)N * ((H + FIRST_R - 1) / FIRST_R) * ((W + 256 / G - 1) / (256 / G));
+    const int grid = (int)(tiles < MAX_GRID ? tiles : MAX_GRID);
+    const size_t lds1 = reduce_lds_bytes(G, 2 * epv), lds2 = reduce_lds_bytes(G, epv);
+#define LP1(T, R) hipLaunchKernelGGL((first1_bn_bwd_kernel<T, R, 1>), dim3(grid), dim3(256), lds1, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, nullptr, nullptr, N, H, W, Cout, acc_ws, nullptr)
+#define LP2(T, R) hipLaunchKernelGGL((first1_bn_bwd_kernel<T, R, 2>), dim3(grid), dim3(256), lds2, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, c1, c2, N, H, W, Cout, dbacc, wacc)
+    if (dtype == UNET_BF16) { if (relu) LP1(__bf16, true); else LP1(__bf16, false); }
+    else { if (relu) LP1(float, true); else LP1(float, false); }
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, (double)N * H * W, Cout, frozen, dgamma, dbeta, c1, c2);
+    UNET_LAUNCH_CHECK();
+    if (dtype == UNET_BF16) { if (relu) LP2(__bf16, true); else LP2(__bf16, false); }
+    else { if (relu) LP2(float, true); else LP2(float, false); }
+    UNET_LAUNCH_CHECK();
+#undef LP1
+#undef LP2
+    hipLaunchKernelGGL(first1_store_kernel, dim3((Cout * 9 + 255) / 256), dim3(256), 0, s, dbacc, wacc, Cout, dbias, dw);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+static int lanes_per_pixel2(int G) { int lp = 1; while (lp < G) lp <<= 1; return lp; }
+
+extern "C" int unet_affine_act_out(int dtype, int relu, const void* z, int ldz, int zoff, const float* scale, const float* shift,
+                                   const float* w, const float* bias, float* logits, void* y /* nullable */, int ldy, int yoff,
+                                   long long M, long long HW, int C, int K, void* stream) {
+    UNET_CHECK(dtype == UNET_F32 || dtype == UNET_BF16, "bad dtype %d", dtype);
+    const int epv = dtype == UNET_BF16 ? 8 : 4;
+    UNET_CHECK(C % 8 == 0 && C / epv <= 64, "affine_act_out: C=%d must be a multiple of 8 and at most %d", C, 64 * epv);
+    UNET_CHECK(K >= 1 && K <= 4, "affine_act_out: 1..4 classes (got %d); use unet_affine_act + unet_conv_out_fwd", K);
+    UNET_CHECK(z && scale && shift && w && logits && HW > 0 && M % HW == 0, "affine_act_out: bad arguments");
+    UNET_CHECK(ldz % 8 == 0 && zoff % 8 == 0 && (y == nullptr || (ldy % 8 == 0 && yoff % 8 == 0)), "affine_act_out: strides/offsets must be multiples of 8");
+    const int LP = lanes_per_pixel2(C / epv);
+    const int grid = ef_grid(M, 256 / LP);
+    hipStream_t s = (hipStream_t)stream;
+#define LO(T, KK, R) hipLaunchKernelGGL((affine_act_out_kernel<T, KK, R>), dim3(grid), dim3(256), 0, s, (const T*)z, ldz, zoff, scale, shift, w, bias, logits, (T*)y, ldy, yoff, M, HW, C, LP)
+#define LOK(KK) case KK: if (dtype == UNET_BF16) { if (relu & 1) LO(__bf16, KK, true); else LO(__bf16, KK, false); } \
+                         else { if (relu & 1) LO(float, KK, true); else LO(float, KK, false); } break;
+    switch (K) { LOK(1) LOK(2) LOK(3) LOK(4) }
+#undef LO
+#undef LOK
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_bn_relu_bwd_out(int dtype, int relu, const float* dlogits, const float* w, int K, long long HW,
+                                    const void* z, int ldz, int zoff, void* dz, int ldo, int ooff,
+                                    const float* scale, const float* shift, const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, float* dbias /* nullable */, float* dw /* [K][C] */, float* db /* [K] */,
+                                    float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C + K*C + K doubles */,
+                                    long long M, int C, void* stream) {
+    if (ef_check(dtype, C, "bn_relu_bwd_out")) return -1;
+    UNET_CHECK(K >= 1 && K <= 4, "bn_relu_bwd_out: 1..4 classes (got %d); use unet_conv_out_bwd + unet_bn_relu_bwd", K);
+    UNET_CHECK(dlogits && w && z && dz && scale && shift && mean && invstd && dgamma && dbeta && dw && db && c1c2_ws && acc_ws,
+               "bn_relu_bwd_out: null argument");
+    UNET_CHECK(HW > 0 && M % HW == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0, "bn_relu_bwd_out: bad shape");
+    const int frozen = (relu >> 1) & 1;
+    relu &= 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int epv = dtype == UNET_BF16 ? 8 : 4, G = C / epv, PL = 256 / G;
+    const int nacc = 3 * C + K * C + K;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * nacc, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    double* dbacc = acc_ws + 2 * C;
+    double* oacc = acc_ws + 3 * C;
+    float* c1 = c1c2_ws; float* c2 = c1c2_ws + C;
+    const int grid = ef_grid(M, PL);
+    size_t lds1 = reduce_lds_bytes(G, 2 * epv);
+    if (lds1 < (size_t)PL * K * sizeof(float)) lds1 = (size_t)PL * K * sizeof(float);
+    const size_t lds2 = reduce_lds_bytes(G, epv);
+#define L1(T, KK, R) hipLaunchKernelGGL((bn_bwd_out_kernel<T, KK, R, 1>), dim3(grid), dim3(256), lds1, s, dlogits, w, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, nullptr, nullptr, M, HW, C, acc_ws, oacc)
+#define L2(T, KK, R) hipLaunchKernelGGL((bn_bwd_out_kernel<T, KK, R, 2>), dim3(grid), dim3(256), lds2, s, dlogits, w, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, c1, c2, M, HW, C, dbacc, nullptr)
+#define LK(LL, KK) case KK: if (dtype == UNET_BF16) { if (relu) LL(__bf16, KK, true); else LL(__bf16, KK, false); } \
+                            else { if (relu) LL(float, KK, true); else LL(float, KK, false); } break;
+    switch (K) { LK(L1, 1) LK(L1, 2) LK(L1, 3) LK(L1, 4) }
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)M, C, frozen, dgamma, dbeta, c1, c2);
+    UNET_LAUNCH_CHECK();
+    switch (K) { LK(L2, 1) LK(L2, 2) LK(L2, 3) LK(L2, 4) }
+    UNET_LAUNCH_CHECK();
+#undef L1
+#undef L2
+#undef LK
+    hipLaunchKernelGGL(out_store_kernel, dim3((K * C + K + 255) / 256), dim3(256), 0, s, oacc, K * C + K, dw, K * C, db);
+    UNET_LAUNCH_CHECK();
+    if (dbias != nullptr) {
+        hipLaunchKernelGGL(acc_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dbacc, dbias, C, 0);
+        UNET_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -46,6 +46,10 @@ class UNetEngine:
         self.fused_pool_bwd = True   # UNet: dy of an encoder level is never stored (ops.PoolGrad)
         self.fused_pool_fwd = True   # UNet: max-pool fused into the BN+ReLU pass of the level's second conv
         self._pooled = None
+        # The two ends of the network fused into their BatchNorm passes (csrc/edge_fused.hip): the first conv's output and the
+        # last activation / its gradient are recomputed inside the bandwidth-bound passes instead of stored (plain UNet,
+        # in_channels = 1, <= 4 classes; anything else takes the separate kernels).  False: the separate kernels (tests).
+        self.fuse_edges = os.environ.get("UNET_AMD_FUSE_EDGES", "1") != "0"
         self.keep_saved = False      # tests: leave the last forward's saved activations in self.last_saved
         self.last_saved = None
         # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
@@ -135,8 +139,10 @@ class UNetEngine:
 
     # ------------------------------------------------------------------ forward
     def _conv_bn_relu(self, P, B, prefix, idx, xin, yout: Optional[Act], dt, train, save, first=False, x_f32=None,
-                      pool=False):
-        """conv3x3(+bias) -> BN -> ReLU.  Returns (y Act, saved record)."""
+                      pool=False, out_head=None):
+        """conv3x3(+bias) -> BN -> ReLU.  Returns (y Act, saved record).
+        out_head = (w (K,C), b): the final 1x1 conv rides on this layer's BN+ReLU pass; the logits are left in
+        self._logits and y is not materialised (returns None for it)."""
         wname, bname = f"{prefix}.double_conv.{idx}.weight", f"{prefix}.double_conv.{idx}.bias"
         bnp = f"{prefix}.double_conv.{idx + 1}"
         w, b = P[wname], P[bname]
@@ -150,6 +156,28 @@ class UNetEngine:
             ops.conv_fwd(xin, wp, bf, y, 3, 3, w.shape[1], Cout, relu=True)
             self._pooled = ops.maxpool_fwd(y) if pool else None
             return y, None
+        fuse_first = (first and self.fuse_edges and x_f32.shape[3] == 1 and tuple(w.shape[2:]) == (3, 3) and not pool
+                      and type(self) is UNetEngine)
+        if fuse_first:
+            # conv output never stored: statistics-only pass, then conv + BN + ReLU in one pass; backward recomputes it
+            N, H, W_, _ = x_f32.shape
+            gamma, beta = P[bnp + ".weight"].detach(), P[bnp + ".bias"].detach()
+            if train:
+                self._stats_gen += 1
+                rows = ops.conv_first_stats(x_f32, w.detach(), b.detach(), dt)
+                st = ops.bn_finalize(rows, N * H * W_, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
+                                     B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
+            else:
+                st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS, for_backward=save)
+            y = yout if yout is not None else ops.dense(N, H, W_, Cout, dt, dev)
+            ops.first_bn_act(x_f32, w.detach(), b.detach(), st, y, relu=True)
+            rec = None
+            if save:
+                rec = _Saved()
+                rec.xin, rec.x_f32, rec.z, rec.st, rec.first = xin, x_f32, None, st, True
+                rec.wname, rec.bname, rec.bnp = wname, bname, bnp
+                rec.fused_first = True
+            return y, rec
         if first:
             N, H, W_, _ = x_f32.shape
             z = ops.dense(N, H, W_, Cout, dt, dev)
@@ -165,23 +193,29 @@ class UNetEngine:
                                  B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
         else:
             st = ops.bn_eval_coeffs(gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"], BN_EPS, for_backward=save)
-        y = yout if yout is not None else ops.dense(z.N, z.H, z.W, Cout, dt, dev)
-        if pool:        # encoder level: the 2x2 max-pool rides on the BN+ReLU pass
-            self._pooled = ops.affine_act_pool(z, y, st, relu=True)
+        if out_head is not None:
+            # last layer: logits = W relu(bn(z)) + b in one pass; the activation is recomputed by the backward passes
+            self._logits = ops.affine_act_out(z, st, out_head[0], out_head[1], relu=True)
+            y = None
         else:
-            ops.affine_act(z, y, st, relu=True)
+            y = yout if yout is not None else ops.dense(z.N, z.H, z.W, Cout, dt, dev)
+            if pool:        # encoder level: the 2x2 max-pool rides on the BN+ReLU pass
+                self._pooled = ops.affine_act_pool(z, y, st, relu=True)
+            else:
+                ops.affine_act(z, y, st, relu=True)
         rec = None
         if save:
             rec = _Saved()
             rec.xin, rec.x_f32, rec.z, rec.st, rec.first = xin, x_f32, z, st, first
             rec.wname, rec.bname, rec.bnp = wname, bname, bnp
+            rec.fused_first = False
         return y, rec
 
-    def block_fwd(self, P, B, prefix, xin, yout, dt, train, save, x_f32=None, pool=False):
+    def block_fwd(self, P, B, prefix, xin, yout, dt, train, save, x_f32=None, pool=False, out_head=None):
         """One DoubleConv (models/unet.py:9-16).  Returns (output Act, saved record); with pool=True the 2x2
         max-pool of the output (pooled Act, code) is left in self._pooled."""
         y1, r1 = self._conv_bn_relu(P, B, prefix, 0, xin, None, dt, train, save, first=x_f32 is not None, x_f32=x_f32)
-        y2, r2 = self._conv_bn_relu(P, B, prefix, 3, y1, yout, dt, train, save, pool=pool)
+        y2, r2 = self._conv_bn_relu(P, B, prefix, 3, y1, yout, dt, train, save, pool=pool, out_head=out_head)
         return y2, ((r1, r2) if save else None)
 
     def block_param_names(self, prefix):
@@ -212,6 +246,11 @@ class UNetEngine:
             sv.blocks, sv.codes, sv.cats, sv.up_in = {}, [], [], []
             sv.dt, sv.shape = dt, (N, H, W)
 
+        # the final 1x1 conv rides on the last BN+ReLU pass whenever that pass exists as a separate kernel (training, or
+        # eval with gradients; the no-grad inference path folds BN into the conv and keeps its own epilogue)
+        fuse_out = (self.fuse_edges and type(self) is UNetEngine and (train or save or not self.fold_bn_eval)
+                    and ops.fused_out_classes_ok(self.n_classes, self.features[0], dt))
+        self._logits = None
         cats: List[torch.Tensor] = []
         cur: Optional[Act] = None
         h, w = H, W
@@ -244,28 +283,41 @@ class UNetEngine:
             ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), Act(cat, f, f), 1, 1,
                          2 * f, 4 * f, epi=1)
             p = f"ups.{2 * j + 1}"
-            cur, rec = self.block_fwd(P, B, p, Act(cat, 0, 2 * f), None, dt, train, save)
+            head = None
+            if j == L - 1 and fuse_out:
+                head = (P["final_conv.weight"].detach().view(self.n_classes, -1).contiguous(), P["final_conv.bias"].detach())
+            cur, rec = self.block_fwd(P, B, p, Act(cat, 0, 2 * f), None, dt, train, save, out_head=head) if head is not None \
+                else self.block_fwd(P, B, p, Act(cat, 0, 2 * f), None, dt, train, save)
             if save:
                 sv.blocks[p] = rec
-        logits = ops.conv_out_fwd(cur, P["final_conv.weight"].detach().view(self.n_classes, -1).contiguous(),
-                                  P["final_conv.bias"].detach())
+        if fuse_out:
+            logits, self._logits = self._logits, None
+        else:
+            logits = ops.conv_out_fwd(cur, P["final_conv.weight"].detach().view(self.n_classes, -1).contiguous(),
+                                      P["final_conv.bias"].detach())
         if save:
+            sv.fused_out = fuse_out
             sv.last, sv.cats = cur, cats
             if self.keep_saved:
                 self.last_saved = sv
         return logits, sv
 
     # ------------------------------------------------------------------ backward
-    def block_bwd(self, P, sv, prefix, dy: Act, grads: Dict[str, torch.Tensor], dt, need_dx=True,
+    def block_bwd(self, P, sv, prefix, dy, grads: Dict[str, torch.Tensor], dt, need_dx=True,
                   split_f: int = 0):
-        """Backward of one DoubleConv.  Returns dx (Act), or (dskip, dup) when split_f > 0."""
+        """Backward of one DoubleConv.  Returns dx (Act), or (dskip, dup) when split_f > 0.
+        dy: an Act, an ops.PoolGrad, or -- last block of the fused output head -- the fp32 NCHW logit gradient."""
         r1, r2 = sv.blocks[prefix]
         dev = r2.z.buf.device
         ws = self.ws(dev)
         # second conv
         z2 = r2.z
         dz2 = ops.dense(z2.N, z2.H, z2.W, z2.C, dt, dev)
-        if isinstance(dy, ops.PoolGrad):      # encoder level: un-pool + skip add happen inside the BN backward passes
+        if isinstance(dy, torch.Tensor):      # fused output head: dy = W^T dlogits is recomputed inside the BN backward passes
+            wf = P["final_conv.weight"]
+            dg, db_, dbias, dwf, dbf = ops.bn_relu_bwd_out(dy, wf.detach().view(self.n_classes, -1).contiguous(), z2, dz2, r2.st, ws)
+            grads["final_conv.weight"], grads["final_conv.bias"] = dwf.view_as(wf), dbf
+        elif isinstance(dy, ops.PoolGrad):    # encoder level: un-pool + skip add happen inside the BN backward passes
             dg, db_, dbias = ops.bn_relu_bwd_pool(dy, z2, dz2, r2.st, ws)
         else:
             dg, db_, dbias = ops.bn_relu_bwd(dy, z2, dz2, r2.st, ws)
@@ -276,12 +328,18 @@ class UNetEngine:
         ops.conv_fwd(dz2, self.packed(r2.wname, w2, 1, dt), None, dy1, 3, 3, w2.shape[0], w2.shape[1])
         del dz2
         # first conv
+        w1 = P[r1.wname]
+        if getattr(r1, "fused_first", False):
+            # first layer of the network: its conv output is recomputed from the image inside both BN backward passes and
+            # the weight gradient comes out of the second one (nothing but the per-channel gradients is written)
+            dg, db_, dbias, dw1 = ops.first_bn_relu_bwd(dy1, r1.x_f32, w1.detach(), P[r1.bname].detach(), r1.st, ws)
+            grads[r1.bnp + ".weight"], grads[r1.bnp + ".bias"], grads[r1.bname], grads[r1.wname] = dg, db_, dbias, dw1
+            return None
         z1 = r1.z
         dz1 = ops.dense(z1.N, z1.H, z1.W, z1.C, dt, dev)
         dg, db_, dbias = ops.bn_relu_bwd(dy1, z1, dz1, r1.st, ws)
         grads[r1.bnp + ".weight"], grads[r1.bnp + ".bias"], grads[r1.bname] = dg, db_, dbias
         del dy1
-        w1 = P[r1.wname]
         if r1.first:
             grads[r1.wname] = self.wgrad_async(dev, lambda w_: ops.conv_first_wgrad(dz1, r1.x_f32, 3, 3, w_), [dz1.buf, r1.x_f32])
             return None
@@ -316,14 +374,19 @@ class UNetEngine:
 
         dlogits = dlogits.contiguous().float()
         wf = P["final_conv.weight"]
-        dcur, dwf, dbf = ops.conv_out_bwd(dlogits, sv.last, wf.detach().view(self.n_classes, -1).contiguous(), ws)
-        grads["final_conv.weight"], grads["final_conv.bias"] = dwf.view_as(wf), dbf
-        emit(["final_conv.weight", "final_conv.bias"])
+        if getattr(sv, "fused_out", False):
+            dcur = dlogits              # block_bwd of the last decoder block consumes the logit gradient directly
+        else:
+            dcur, dwf, dbf = ops.conv_out_bwd(dlogits, sv.last, wf.detach().view(self.n_classes, -1).contiguous(), ws)
+            grads["final_conv.weight"], grads["final_conv.bias"] = dwf.view_as(wf), dbf
+            emit(["final_conv.weight", "final_conv.bias"])
         dskips = [None] * L
         for j in reversed(range(L)):
             f = list(reversed(self.features))[j]
             p = f"ups.{2 * j + 1}"
             res = self.block_bwd(P, sv, p, dcur, grads, dt, split_f=f)
+            if j == L - 1 and getattr(sv, "fused_out", False):
+                emit(["final_conv.weight", "final_conv.bias"])
             dskip, dup = res[0], res[1]
             emit(self.block_param_names(p))
             dskips[L - 1 - j] = dskip

@@ -317,6 +317,99 @@ def conv_first_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return rows
 
 
+def conv_first_stats(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], dt: int) -> torch.Tensor:
+    """BN partial rows of the Cin = 1 3x3 first conv WITHOUT storing its output (the fused first layer recomputes it)."""
+    _need_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if Cin != 1 or tuple(w.shape) != (Cout, 1, 3, 3) or x.dtype != torch.float32 or not x.is_contiguous() \
+            or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("first conv statistics: fp32 [N,H,W,1] input and (Cout,1,3,3) weights expected")
+    nrows = lib().unet_conv_first_rows(dt, N, H, W, Cout)
+    if nrows <= 0:
+        raise UNetHipError("first conv: unsupported Cout")
+    rows = torch.empty((nrows, Cout, 2), dtype=torch.float32, device=x.device)
+    check(lib().unet_conv_first_fwd(dt, 3, 3, _p(x), _p(w), _p(bias), None, _p(rows), N, H, W, 1, Cout, _stream()), "conv_first_stats")
+    return rows
+
+
+def first_bn_act(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], st: "BNState", y: Act, relu=True):
+    """y = act(scale * conv3x3(x) + shift) for the Cin = 1 first layer in one pass (the conv output is not stored)."""
+    _need_cuda(x, w)
+    y.check()
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if Cin != 1 or tuple(w.shape) != (Cout, 1, 3, 3) or (y.N, y.H, y.W, y.C) != (N, H, W, Cout) or st.scale.numel() != Cout:
+        raise UNetHipError("first_bn_act: shape mismatch")
+    if x.dtype != torch.float32 or not x.is_contiguous() or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("first_bn_act: fp32 contiguous input and weights expected")
+    check(lib().unet_first_bn_act(y.dt, 1 if relu else 0, _p(x), _p(w), _p(bias), _p(st.scale), _p(st.shift), _p(y.buf), y.ld, y.off,
+                                  N, H, W, Cout, _stream()), "first_bn_act")
+
+
+def first_bn_relu_bwd(dy: Act, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], st: "BNState", ws: "Workspace",
+                      relu=True):
+    """BN(+ReLU) backward of the fused first layer -> (dgamma, dbeta, dbias, dw (Cout,1,3,3)); nothing else is written."""
+    dy.check()
+    _need_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if Cin != 1 or tuple(w.shape) != (Cout, 1, 3, 3) or (dy.N, dy.H, dy.W, dy.C) != (N, H, W, Cout):
+        raise UNetHipError("first_bn_relu_bwd: shape mismatch")
+    if x.dtype != torch.float32 or not x.is_contiguous() or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("first_bn_relu_bwd: fp32 contiguous input and weights expected")
+    if 12 * Cout > ws.acc.numel() or 2 * Cout > ws.c1c2.numel():
+        raise UNetHipError("first_bn_relu_bwd: workspace too small")
+    g = torch.empty((3, Cout), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=x.device)
+    check(lib().unet_first_bn_relu_bwd(dy.dt, _bn_bwd_flags(st, relu), _p(dy.buf), dy.ld, dy.off, _p(x), _p(w), _p(bias),
+                                       _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(g[0]), _p(g[1]), _p(g[2]), _p(dw),
+                                       _p(ws.c1c2), _p(ws.acc), N, H, W, Cout, _stream()), "first_bn_relu_bwd")
+    return g[0], g[1], g[2], dw
+
+
+def affine_act_out(z: Act, st: "BNState", w: torch.Tensor, bias: Optional[torch.Tensor], relu=True,
+                   y: Optional[Act] = None) -> torch.Tensor:
+    """logits (fp32 NCHW) = W act(scale*z + shift) + b in one pass; the activation is written only if `y` is given."""
+    z.check()
+    K, C = w.shape[0], w.shape[1]
+    if C != z.C or w.dtype != torch.float32 or not w.is_contiguous() or st.scale.numel() != C:
+        raise UNetHipError("affine_act_out: shape mismatch")
+    if y is not None:
+        y.check()
+        if y.C != C or y.M != z.M or y.dt != z.dt:
+            raise UNetHipError("affine_act_out: activation buffer shape mismatch")
+    logits = torch.empty((z.N, K, z.H, z.W), dtype=torch.float32, device=z.buf.device)
+    check(lib().unet_affine_act_out(z.dt, 1 if relu else 0, _p(z.buf), z.ld, z.off, _p(st.scale), _p(st.shift), _p(w), _p(bias),
+                                    _p(logits), _p(y.buf) if y is not None else None, y.ld if y is not None else 0,
+                                    y.off if y is not None else 0, z.M, z.H * z.W, C, K, _stream()), "affine_act_out")
+    return logits
+
+
+def fused_out_classes_ok(K: int, C: int, dt: int) -> bool:
+    return 1 <= K <= 4 and C % 8 == 0 and C // (8 if dt == BF16 else 4) <= 64
+
+
+def bn_relu_bwd_out(dlogits: torch.Tensor, w: torch.Tensor, z: Act, dz: Act, st: "BNState", ws: "Workspace", relu=True):
+    """BN(+ReLU) backward of the last layer with dy = W^T dlogits recomputed -> (dgamma, dbeta, dbias, dW (K,C), db (K))."""
+    z.check(); dz.check()
+    K, C = w.shape[0], w.shape[1]
+    if C != z.C or dz.C != C or dz.M != z.M or dz.dt != z.dt or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("bn_relu_bwd_out: shape mismatch")
+    if dlogits.dtype != torch.float32 or not dlogits.is_contiguous() or tuple(dlogits.shape) != (z.N, K, z.H, z.W):
+        raise UNetHipError("bn_relu_bwd_out: dlogits must be contiguous fp32 NCHW")
+    if 3 * C + K * C + K > ws.acc.numel() or 2 * C > ws.c1c2.numel():
+        raise UNetHipError("bn_relu_bwd_out: workspace too small")
+    g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
+    dw = torch.empty((K, C), dtype=torch.float32, device=z.buf.device)
+    db = torch.empty((K,), dtype=torch.float32, device=z.buf.device)
+    check(lib().unet_bn_relu_bwd_out(z.dt, _bn_bwd_flags(st, relu), _p(dlogits), _p(w), K, z.H * z.W, _p(z.buf), z.ld, z.off,
+                                     _p(dz.buf), dz.ld, dz.off, _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                     _p(g[0]), _p(g[1]), _p(g[2]), _p(dw), _p(db), _p(ws.c1c2), _p(ws.acc), z.M, C, _stream()),
+          "bn_relu_bwd_out")
+    return g[0], g[1], g[2], dw, db
+
+
 def conv_first_wgrad(dz: Act, x: torch.Tensor, kh: int, kw: int, ws: Workspace) -> torch.Tensor:
     dz.check()
     N, H, W, Cin = x.shape
