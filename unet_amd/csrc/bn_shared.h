@@ -4,6 +4,9 @@
 #include "common.h"
 
 #define MAX_GRID 2048
+// Workgroups of a streaming (HBM-bound, grid-stride) kernel: 4 per CU.  More resident workgroups LOWER the achieved HBM rate
+// on this part (8 per CU: 4.97 TB/s, 3-4 per CU: 5.25-5.44 on a 2.1 GB read+write pass); UNET_AMD_BN_GRID overrides (experiments).
+#define STREAM_GRID_CAP 1024
 
 struct ChanMap {
     int G, PL, pl, cg;

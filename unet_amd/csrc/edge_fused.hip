@@ -18,6 +18,7 @@
 // dy, dz0) is rounded to T here at the same point (round_to<T>), so the two paths agree to the last bit except for the
 // order of fp64 atomic adds.
 #include "bn_shared.h"
+#include <cstdlib>
 
 // =================================================================================================
 // first layer
@@ -362,9 +363,13 @@ static __global__ void out_store_kernel(const double* __restrict__ oacc, int n, 
 }
 
 // =================================================================================================
+static inline int ef_cap() {
+    static const int v = [] { const char* e = getenv("UNET_AMD_BN_GRID"); const int g = e ? atoi(e) : 0; return g > 0 ? g : STREAM_GRID_CAP; }();
+    return v;
+}
 static inline int ef_grid(long long M, int PL) {
     long long g = (M + PL - 1) / PL;
-    if (g > MAX_GRID) g = MAX_GRID;
+    if (g > ef_cap()) g = ef_cap();
     if (g < 1) g = 1;
     return (int)g;
 }

@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "bn_shared.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------
 // BN statistics: reduce the conv epilogue's per-tile (sum, sumsq) rows into fp64 totals.
@@ -134,6 +135,13 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
     if (invstd_out != nullptr) invstd_out[c] = invstd;
 }
 
+// STREAMING SHAPE of the per-channel kernels below (measured on 32 x 512^2 x 64 bf16, tools/exp_affine.py history in DESIGN
+// 9): HBM throughput peaks with FEW resident workgroups that each keep SEVERAL 16-byte requests per thread in flight --
+// 2 workgroups per CU x 2 pixels per trip reached 5.7 TB/s where 8 per CU x 1 reached 4.97 (and grids that are not a
+// multiple of the 256 CUs lose up to 15 % to the uneven tail).  STREAM_U pixels are therefore loaded before any is used, and
+// the launchers cap the grid at stream_grid_cap() workgroups.
+#define STREAM_U 2
+
 // y = relu(z*scale + shift)   (relu optional)
 template <typename T, bool RELU>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z, int ldz, int zoff,
@@ -146,16 +154,27 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z
     float sc[EPV], sh[EPV];
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { sc[e] = scale[m.cg * EPV + e]; sh[e] = shift[m.cg * EPV + e]; }
-    for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
-        const uint4 v = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
-        float f[EPV];
-        Vec16<T>::unpack(v, f);
+    const long long stride = (long long)gridDim.x * m.PL;
+    for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * STREAM_U) {
+        uint4 v[STREAM_U];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            f[e] = fmaf(f[e], sc[e], sh[e]);
-            if (RELU) f[e] = fmaxf(f[e], 0.f);
+        for (int u = 0; u < STREAM_U; ++u) {
+            const long long p = p0 + u * stride;
+            if (p < M) v[u] = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
         }
-        *(uint4*)(y + p * ldy + yoff + m.cg * EPV) = Vec16<T>::pack(f);
+#pragma unroll
+        for (int u = 0; u < STREAM_U; ++u) {
+            const long long p = p0 + u * stride;
+            if (p >= M) break;
+            float f[EPV];
+            Vec16<T>::unpack(v[u], f);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                f[e] = fmaf(f[e], sc[e], sh[e]);
+                if (RELU) f[e] = fmaxf(f[e], 0.f);
+            }
+            *(uint4*)(y + p * ldy + yoff + m.cg * EPV) = Vec16<T>::pack(f);
+        }
     }
 }
 
@@ -165,30 +184,37 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ z
 // never written and read back (the two passes read 2.75 B/element more, the un-pool kernel's 4.75 B/element go away).
 struct PoolSrc { const void* dpool; const uint8_t* code; int H, W; };
 
+template <typename T> struct DyRaw { uint4 d, g; uint2 code; unsigned k; };
+
+// issue the loads of one pixel's dy (nothing is unpacked yet, so several pixels' requests can be in flight together)
 template <typename T, bool POOL>
-__device__ __forceinline__ void load_dy(const T* __restrict__ dy, int ldd, int doff, const PoolSrc& ps, long long p, int cg, int C,
-                                        float (&fd)[TT<T>::EPV]) {
+__device__ __forceinline__ DyRaw<T> fetch_dy(const T* __restrict__ dy, int ldd, int doff, const PoolSrc& ps, long long p, int cg, int C) {
     constexpr int EPV = TT<T>::EPV;
-    Vec16<T>::unpack(*(const uint4*)(dy + p * ldd + doff + cg * EPV), fd);
+    DyRaw<T> r;
+    r.d = *(const uint4*)(dy + p * ldd + doff + cg * EPV);
     if (POOL) {
         const int pi = (int)p;
         const int w = pi % ps.W, t = pi / ps.W, h = t % ps.H, n = t / ps.H;
         const long long o = (((long long)n * (ps.H >> 1) + (h >> 1)) * (ps.W >> 1) + (w >> 1)) * C + cg * EPV;
-        const unsigned k = (unsigned)(2 * (h & 1) + (w & 1));
+        r.k = (unsigned)(2 * (h & 1) + (w & 1));
+        r.g = *(const uint4*)((const T*)ps.dpool + o);
+        if (EPV == 8) r.code = *(const uint2*)(ps.code + o);
+        else { r.code.x = *(const uint32_t*)(ps.code + o); r.code.y = 0; }
+    }
+    return r;
+}
+
+template <typename T, bool POOL>
+__device__ __forceinline__ void finish_dy(const DyRaw<T>& r, float (&fd)[TT<T>::EPV]) {
+    constexpr int EPV = TT<T>::EPV;
+    Vec16<T>::unpack(r.d, fd);
+    if (POOL) {
         float g[EPV];
-        Vec16<T>::unpack(*(const uint4*)((const T*)ps.dpool + o), g);
-        if (EPV == 8) {
-            const uint2 pk = *(const uint2*)(ps.code + o);
+        Vec16<T>::unpack(r.g, g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (((pk.x >> (8 * e)) & 0xff) == k) fd[e] += g[e];
-                if (((pk.y >> (8 * e)) & 0xff) == k) fd[(4 + e) % EPV] += g[(4 + e) % EPV];
-            }
-        } else {
-            const uint32_t pk = *(const uint32_t*)(ps.code + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (((pk >> (8 * e)) & 0xff) == k) fd[e] += g[e];
+        for (int e = 0; e < 4; ++e) {
+            if (((r.code.x >> (8 * e)) & 0xff) == r.k) fd[e] += g[e];
+            if (EPV == 8 && ((r.code.y >> (8 * e)) & 0xff) == r.k) fd[(4 + e) % EPV] += g[(4 + e) % EPV];
         }
     }
 }
@@ -212,15 +238,30 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(PoolSrc ps, const T*
             const int c = m.cg * EPV + e;
             sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
         }
-        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
-            float fz[EPV], fd[EPV];
-            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
-            load_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C, fd);
+        const long long stride = (long long)gridDim.x * m.PL;
+        for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * STREAM_U) {
+            uint4 vz[STREAM_U];
+            DyRaw<T> vd[STREAM_U];
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
-                part[e] += d;
-                part[EPV + e] += d * ((fz[e] - mu[e]) * is[e]);
+            for (int u = 0; u < STREAM_U; ++u) {
+                const long long p = p0 + u * stride;
+                if (p < M) {
+                    vz[u] = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
+                    vd[u] = fetch_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < STREAM_U; ++u) {
+                if (p0 + u * stride >= M) break;
+                float fz[EPV], fd[EPV];
+                Vec16<T>::unpack(vz[u], fz);
+                finish_dy<T, POOL>(vd[u], fd);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                    part[e] += d;
+                    part[EPV + e] += d * ((fz[e] - mu[e]) * is[e]);
+                }
             }
         }
     }
@@ -249,23 +290,39 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
             const int c = m.cg * EPV + e;
             sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; k1[e] = c1[c]; k2[e] = c2[c];
         }
-        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
-            float fz[EPV], fd[EPV];
-            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
-            load_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C, fd);
+        const long long stride = (long long)gridDim.x * m.PL;
+        for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * STREAM_U) {
+            uint4 vz[STREAM_U];
+            DyRaw<T> vd[STREAM_U];
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
-                const float xh = (fz[e] - mu[e]) * is[e];
-                fd[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+            for (int u = 0; u < STREAM_U; ++u) {
+                const long long p = p0 + u * stride;
+                if (p < M) {
+                    vz[u] = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
+                    vd[u] = fetch_dy<T, POOL>(dy, ldd, doff, ps, p, m.cg, C);
+                }
             }
-            const uint4 o = Vec16<T>::pack(fd);
-            *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = o;
-            if (dbias_acc != nullptr) {
-                float fr[EPV];
-                Vec16<T>::unpack(o, fr);          // sum what the consumers of dz will actually read
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+            for (int u = 0; u < STREAM_U; ++u) {
+                const long long p = p0 + u * stride;
+                if (p >= M) break;
+                float fz[EPV], fd[EPV];
+                Vec16<T>::unpack(vz[u], fz);
+                finish_dy<T, POOL>(vd[u], fd);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float d = (!RELU || fmaf(fz[e], sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                    const float xh = (fz[e] - mu[e]) * is[e];
+                    fd[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+                }
+                const uint4 o = Vec16<T>::pack(fd);
+                *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = o;
+                if (dbias_acc != nullptr) {
+                    float fr[EPV];
+                    Vec16<T>::unpack(o, fr);          // sum what the consumers of dz will actually read
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+                }
             }
         }
     }
@@ -452,9 +509,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+static inline int stream_grid_cap() {
+    static const int v = [] { const char* e = getenv("UNET_AMD_BN_GRID"); const int g = e ? atoi(e) : 0; return g > 0 ? g : STREAM_GRID_CAP; }();
+    return v;
+}
 static inline int grid_for(long long M, int PL) {
     long long g = (M + PL - 1) / PL;
-    if (g > MAX_GRID) g = MAX_GRID;
+    if (g > stream_grid_cap()) g = stream_grid_cap();
     if (g < 1) g = 1;
     return (int)g;
 }
