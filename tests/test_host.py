@@ -34,6 +34,7 @@ def test_host_argument_checks_report_errors_without_a_gpu():
     rc = L.unet_conv_fwd(1, 3, 3, 1, 0, None, None, None, None, None, 1, 8, 8, 16, 16, 0, 8, 8, 8, 8, 0, 1, 1, None, 0, 0, 0, 0, None)
     assert rc != 0 and b"null pointer" in L.unet_last_error()
     assert L.unet_conv_tiles(1, 3, 3, 1, 0, 32, 512, 512, 128, 128, 0, 0) == 32 * 32 * 16 and L.unet_conv_tiles(0, 3, 3, 1, 0, 32, 512, 512, 64, 64, 0, 0) == 32 * 64 * 16
+    assert L.unet_conv_tiles(1, 3, 3, 1, 0, 32, 512, 512, 64, 64, 0, 0) == 256                     # deferred statistics: one row per workgroup
     assert L.unet_conv_tiles(1, 3, 3, 1, 0, 32, 512, 512, 64, 64, 4, 0) == 32 * 32 * 16             # GroupNorm: per-tile rows
     assert L.unet_conv_wgrad_splits(1, 3, 3, 1, 32, 512, 512, 64, 64) >= 256
 

@@ -535,7 +535,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         epilogue(std::integral_constant<bool, fast>{});
         if (h_owed) { push_h(); h_owed = false; }
         if (DEFER && do_stats && !last_tile) {
-            if (tid < BCO * 2) a.stats[((size_t)cur.pt * a.Cout + (tid >> 1)) * 2 + (tid & 1)] = 0.f;      // this tile's sums ride in the last row
+            // nothing to write: this tile's sums ride in the workgroup's one statistics row (written on its last tile)
         } else if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
@@ -543,7 +543,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 float s = 0.f;
 #pragma unroll
                 for (int w = 0; w < C::NWR; ++w) s += red[(w * BCO + ch) * 2 + k];
-                if (cur.cb * BCO + ch < a.Cout) a.stats[((size_t)cur.pt * a.Cout + cur.cb * BCO + ch) * 2 + k] = s;
+                const int row = DEFER ? lblock : cur.pt;            // deferred statistics: one row per workgroup
+                if (cur.cb * BCO + ch < a.Cout) a.stats[((size_t)row * a.Cout + cur.cb * BCO + ch) * 2 + k] = s;
             }
             __syncthreads();
         }
@@ -574,8 +575,20 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     return 0;
 }
 
-// stat rows the bf16 3x3 path writes: one per 16x32 pixel tile
-int conv2_rows(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wout + 31) / 32); }
+static bool conv2_gen(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
+    const int bco = Cout > 64 ? 128 : 64;
+    return (Cin & 31) != 0 || (Cout % bco) != 0 || (Hout & 15) != 0 || (Wout & 31) != 0 || (flags & 1) != 0 || (csplit & 63) != 0;
+}
+// deferred statistics (specialised 64-channel kernel, statistics wanted, not per-image rows): ONE row per workgroup
+static bool conv2_defer(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
+    return Cout <= 64 && !conv2_gen(Cin, Cout, Hout, Wout, flags, csplit) && (flags & 4) == 0;
+}
+// stat rows the bf16 3x3 path writes: one per 16x32 pixel tile, or one per persistent workgroup (deferred statistics)
+int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int csplit) {
+    const int tiles = N * ((Hout + 15) / 16) * ((Wout + 31) / 32);
+    if (conv2_defer(Cin, Cout, Hout, Wout, flags, csplit)) return tiles < 256 ? tiles : 256;
+    return tiles;
+}
 
 // MEASURED AND NOT KEPT (round 2, same-box A/B against this kernel):
 //  * 256-thread workgroups on 8x32-pixel tiles, two per CU, for the HBM-bound 64-channel layers (one workgroup's store
@@ -586,12 +599,11 @@ int conv2_rows(int N, int Hout, int Wout) { return N * ((Hout + 15) / 16) * ((Wo
 //    64-byte runs per pixel and instruction cost more at the memory side than the whole 128-byte lines of the transposed
 //    form (128-channel dgrad into a 2.1 GB tensor: 1.106 -> 1.147 ms).
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
-    const int bco = a.Cout > 64 ? 128 : 64;
-    const bool gen = (a.Cin & 31) != 0 || (a.Cout % bco) != 0 || (a.Hout & 15) != 0 || (a.Wout & 31) != 0 ||
-                     (a.flags & 1) != 0 || (a.csplit & 63) != 0;
+    const bool gen = conv2_gen(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit);
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
     if (gen) return launch_conv2<1, true>(a, s);
     // deferred statistics put a workgroup's sums (over tiles of several images) into one row: not for flags bit 2
-    // (per-tile rows grouped per image, what GroupNorm's finalize reads)
-    return (a.stats != nullptr && (a.flags & 4) == 0) ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false>(a, s);
+    // (per-tile rows grouped per image, what GroupNorm's finalize reads); conv2_rows() tells the host the row count
+    return (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit)) ? launch_conv2<1, false, true>(a, s)
+                                                                                                 : launch_conv2<1, false>(a, s);
 }

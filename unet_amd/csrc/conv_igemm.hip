@@ -251,7 +251,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 }
 
 // bf16 3x3 stride-1 path (conv_fwd2.hip)
-int conv2_rows(int N, int Hout, int Wout);
+int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int csplit);
 int dispatch_conv2(const ConvArgs& a, hipStream_t s);
 // bf16 ConvTranspose2d forward / dgrad on whole tiles (conv_t2.hip)
 bool convT2_fwd_ok(const ConvArgs& a);
@@ -286,7 +286,7 @@ static int dispatch_conv(int kh, int kw, int sh, int epi, const ConvArgs& a, hip
 // stats_count() tells the caller how many partial rows unet_conv_fwd writes: one per pixel tile.
 extern "C" int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout,
                                int Cin, int Cout, int flags, int csplit) {
-    if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_rows(N, Hout, Wout);
+    if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_rows(N, Hout, Wout, Cin, Cout, flags, csplit);
     return N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
 }
 

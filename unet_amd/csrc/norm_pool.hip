@@ -79,7 +79,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, double count,
                         scale, shift, mean_out, invstd_out);
 }
 
-// Few rows (the deep layers: <= 1024 pixel tiles): one launch instead of memset + reduce + finalize.  A workgroup owns
+// Up to 4096 rows (every layer of the 512^2 U-Net but none of its slowest: the 64-channel convs write one row per workgroup):
+// one launch instead of memset + reduce + finalize.  A workgroup owns
 // 8 channels (one 64-byte run per row), its 32 row lanes walk all rows, the partials are added in lane order (no atomics:
 // deterministic) and the channel's first lane finalizes.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ rows, int nrows, int C, double count,
@@ -534,7 +535,7 @@ extern "C" int unet_bn_finalize(const float* stat_rows, int nrows, int C, long l
                                 double* acc_ws /* 2*C doubles */, void* stream) {
     UNET_CHECK(nrows > 0 && C > 0 && count > 0, "bn_finalize: empty problem");
     hipStream_t s = (hipStream_t)stream;
-    if (nrows <= 1024) {
+    if (nrows <= 4096) {
         hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, s, stat_rows, nrows, C, (double)count, gamma, beta,
                            running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, invstd);
         UNET_LAUNCH_CHECK();
