@@ -454,7 +454,10 @@ extern "C" int unet_affine_act_out(int dtype, int relu, const void* z, int ldz, 
     UNET_CHECK(z && scale && shift && w && logits && HW > 0 && M % HW == 0, "affine_act_out: bad arguments");
     UNET_CHECK(ldz % 8 == 0 && zoff % 8 == 0 && (y == nullptr || (ldy % 8 == 0 && yoff % 8 == 0)), "affine_act_out: strides/offsets must be multiples of 8");
     const int LP = lanes_per_pixel2(C / epv);
-    const int grid = ef_grid(M, 256 / LP);
+    // one request per thread per trip and a shuffle reduction behind it: this pass wants MORE resident workgroups than the
+    // read+write streaming passes (8 per CU: 290 us, 4 per CU: 377 us at 32 x 512^2 x 64)
+    long long gl = (M + 256 / LP - 1) / (256 / LP);
+    const int grid = (int)(gl > MAX_GRID ? MAX_GRID : (gl < 1 ? 1 : gl));
     hipStream_t s = (hipStream_t)stream;
 #define LO(T, KK, R) hipLaunchKernelGGL((affine_act_out_kernel<T, KK, R>), dim3(grid), dim3(256), 0, s, (const T*)z, ldz, zoff, scale, shift, w, bias, logits, (T*)y, ldy, yoff, M, HW, C, LP)
 #define LOK(KK) case KK: if (dtype == UNET_BF16) { if (relu & 1) LO(__bf16, KK, true); else LO(__bf16, KK, false); } \
