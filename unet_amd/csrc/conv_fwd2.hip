@@ -39,7 +39,10 @@ struct Cv2Cfg {
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
     static constexpr int RED_BYTES = NWR * BCO * 2 * 4;
     static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
-    static constexpr int SMEM = OFF_BIAS + 2 * 1024;
+    // producer scheme (WC == 2): the per-lane source offsets of each producer wave's 10 halo pieces, [wave][piece][lane]
+    static constexpr int OFF_HOFF = OFF_BIAS + 2 * 1024;
+    static constexpr int HOFF_BYTES = (WC == 2) ? 4 * (H_PIECES / 4) * 256 : 0;
+    static constexpr int SMEM = OFF_HOFF + HOFF_BYTES;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
@@ -120,6 +123,15 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     unsigned hoff[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) hoff[i] = ASYM ? 0u : h_off_calc(wave + 8 * i, lane);
+    // Producer scheme: 10 offsets per lane do not fit the register budget, and recomputing them per piece costs ~15 VALU
+    // instructions that have to squeeze between the SIMD partner's MFMAs (an MFMA holds the vector issue for 8 of its 16
+    // cycles): the in-kernel trace showed 1,700 cycles of refill per phase for 9-10 pieces.  They are computed once into
+    // LDS; a refill reads its 10 words back (wave-private rows: no barrier needed) and spends one select per piece.
+    unsigned* hoff_lds = (unsigned*)(smem + C::OFF_HOFF) + (ASYM ? (wave & 3) * HPW * 64 : 0);
+    if (ASYM && producer) {
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) hoff_lds[i * 64 + lane] = h_off_calc(wave + NPROD * i, lane);
+    }
     constexpr bool generic = GEN;
     const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
     const char* wg = (const char*)a.w;
@@ -188,12 +200,15 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const long long offu = (((long long)t.n * a.Hin + r0) * a.Win + c0) * a.ldx * 2 + c * 64;          // wave-uniform
         if (!producer) return 0;
         const i32x4_t rsrc = make_rsrc(xg + offu, LDS_DMA_RECORDS);
-        int lane_h = lane;
-        if (ASYM) asm volatile("" : "+v"(lane_h));           // keep the offset arithmetic inside the refill
+        unsigned ho[ASYM ? HPW : 1];
+        if (ASYM) {
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) ho[i] = hoff_lds[i * 64 + lane];
+        }
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
             const int piece = wave + NPROD * i;
-            unsigned v = ((mask >> i) & 1u) ? (ASYM ? h_off_calc(piece, lane_h) : hoff[i % 5]) : LDS_DMA_OOB;
+            unsigned v = ((mask >> i) & 1u) ? (ASYM ? ho[i % (ASYM ? HPW : 1)] : hoff[i % 5]) : LDS_DMA_OOB;
             if (generic) {
                 int lane_ = lane;
                 asm volatile("" : "+v"(lane_));
