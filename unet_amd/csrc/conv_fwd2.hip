@@ -32,7 +32,7 @@ struct Cv2Cfg {
     static constexpr int HREC = (TH + 2) * HP;     // 612 records
     static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
     static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: one kernel row; the whole kernel for 64-channel tiles
+    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: one kernel column (kw); the whole kernel for 64-channel tiles
     static constexpr int NPH = 9 / TPP;            // phases per 32-channel chunk
     static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
@@ -161,63 +161,77 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         }
         return m;
     };
-    // weights of one phase: taps ph*TPP .. +TPP-1, channels [c*32, c*32+32) of output-channel block cb
+    // weights of one phase: taps of the phase, channels [c*32, c*32+32) of output-channel block cb; a wave's share is
+    // WPW pieces (piece i of wave w = 16 rows of the [TPP][BCO] image starting at row (w + NPROD*i)*16)
+    constexpr int WPW = (C::W_PIECES + NPROD - 1) / NPROD;
+    auto issue_bias = [&](const Tile& t, int bslot) {
+        // the tile's biases ride with its first weights (wave 0, one piece; lanes past the block read zeros)
+        const int nb = min(BCO, a.Cout - t.cb * BCO) * 4;
+        lds_dma16_buf(make_rsrc(a.bias + t.cb * BCO, (unsigned)nb), (unsigned)lane * 16u,
+                      __builtin_amdgcn_readfirstlane(sb + C::OFF_BIAS + bslot * 1024));
+        return 1;
+    };
+    auto issue_w_piece = [&](const Tile& t, int c, int ph, int wstage, int i) {
+        const int p = wave + NPROD * i;
+        if (p >= C::W_PIECES) return 0;
+        const int r0 = p * 16;
+        const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
+        const int tap = (NPH == 1) ? j : j * 3 + ph;                  // a phase of a 128-channel tile is one kernel COLUMN: taps (kh = j, kw = ph)
+        const long long offu = ((long long)(tap * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
+        unsigned v = woff;
+        if (generic) {
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const int dl_ = lane_ >> 2, wq_ = (lane_ & 3) ^ swz64(dl_);
+            v = ((cou + dl_) < a.Cout && (c * 32 + wq_ * 8) < a.Cin) ? woff : LDS_DMA_OOB;
+        }
+        lds_dma16_buf(make_rsrc(wg + offu, LDS_DMA_RECORDS), v,
+                      __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
+        return 1;
+    };
     auto issue_w = [&](const Tile& t, int c, int ph, int wstage, int bslot, bool bias_only) {
         int cnt = 0;
         if (!producer) return cnt;
-        if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) {
-            ++cnt;
-            // the tile's biases ride with its first weights (wave 0, one piece; lanes past the block read zeros)
-            const int nb = min(BCO, a.Cout - t.cb * BCO) * 4;
-            lds_dma16_buf(make_rsrc(a.bias + t.cb * BCO, (unsigned)nb), (unsigned)lane * 16u,
-                          __builtin_amdgcn_readfirstlane(sb + C::OFF_BIAS + bslot * 1024));
-        }
+#ifdef CV2_X_NODMA
+        return cnt;
+#endif
+        if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) cnt += issue_bias(t, bslot);
         if (bias_only) return cnt;
 #pragma unroll
-        for (int i = 0; i < (C::W_PIECES + NPROD - 1) / NPROD; ++i) {
-            const int p = wave + NPROD * i;
-            if (p < C::W_PIECES) {
-                const int r0 = p * 16;
-                const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
-                const long long offu = ((long long)((ph * TPP + j) * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
-                unsigned v = woff;
-                if (generic) {
-                    int lane_ = lane;
-                    asm volatile("" : "+v"(lane_));
-                    const int dl_ = lane_ >> 2, wq_ = (lane_ & 3) ^ swz64(dl_);
-                    v = ((cou + dl_) < a.Cout && (c * 32 + wq_ * 8) < a.Cin) ? woff : LDS_DMA_OOB;
-                }
-                lds_dma16_buf(make_rsrc(wg + offu, LDS_DMA_RECORDS), v,
-                              __builtin_amdgcn_readfirstlane(sb + C::OFF_W + wstage * C::W_BYTES + p * 1024));
-                ++cnt;
-            }
-        }
+        for (int i = 0; i < WPW; ++i) cnt += issue_w_piece(t, c, ph, wstage, i);
         return cnt;
     };
     // input halo of one chunk: rows h0-pad .. +17, cols w0-pad .. +33, channels [c*32, c*32+32)
-    auto issue_h = [&](const Tile& t, int c, int hstage, unsigned mask) {
+    auto halo_rsrc = [&](const Tile& t, int c) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         const long long offu = (((long long)t.n * a.Hin + r0) * a.Win + c0) * a.ldx * 2 + c * 64;          // wave-uniform
+        return make_rsrc(xg + offu, LDS_DMA_RECORDS);
+    };
+    auto issue_h_piece = [&](const i32x4_t rsrc, int c, int hstage, unsigned mask, int i, unsigned off) {
+        const int piece = wave + NPROD * i;
+        unsigned v = ((mask >> i) & 1u) ? off : LDS_DMA_OOB;
+        if (generic) {
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+            const int r = piece * 16 + (lane_ >> 2);
+            const int hr = (r * 241) >> 13, hc = r - hr * HP;
+            if (c * 32 + ((lane_ & 3) ^ swz64(hc)) * 8 >= a.Cin) v = LDS_DMA_OOB;
+        }
+        lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + piece * 1024));
+    };
+    auto issue_h = [&](const Tile& t, int c, int hstage, unsigned mask) {
         if (!producer) return 0;
-        const i32x4_t rsrc = make_rsrc(xg + offu, LDS_DMA_RECORDS);
+#ifdef CV2_X_NODMA
+        return 0;
+#endif
+        const i32x4_t rsrc = halo_rsrc(t, c);
         unsigned ho[ASYM ? HPW : 1];
         if (ASYM) {
 #pragma unroll
             for (int i = 0; i < HPW; ++i) ho[i] = hoff_lds[i * 64 + lane];
         }
 #pragma unroll
-        for (int i = 0; i < HPW; ++i) {
-            const int piece = wave + NPROD * i;
-            unsigned v = ((mask >> i) & 1u) ? (ASYM ? ho[i % (ASYM ? HPW : 1)] : hoff[i % 5]) : LDS_DMA_OOB;
-            if (generic) {
-                int lane_ = lane;
-                asm volatile("" : "+v"(lane_));
-                const int r = piece * 16 + (lane_ >> 2);
-                const int hr = (r * 241) >> 13, hc = r - hr * HP;
-                if (c * 32 + ((lane_ & 3) ^ swz64(hc)) * 8 >= a.Cin) v = LDS_DMA_OOB;
-            }
-            lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + piece * 1024));
-        }
+        for (int i = 0; i < HPW; ++i) issue_h_piece(rsrc, c, hstage, mask, i, ASYM ? ho[i % (ASYM ? HPW : 1)] : hoff[i % 5]);
         return HPW;
     };
 
@@ -333,20 +347,25 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 // ---- this phase: TPP taps -----------------------------------------------------------
                 const char* hb = smem + hs * C::H_BYTES;
                 const char* wb = smem + ws * C::W_BYTES;
-                // steps = (tap j, pixel group pg): 4 MFMAs each.  B fragments run DEPTH steps ahead of
-                // their MFMAs in a small register ring; the next tap's A fragments are requested half a
-                // tap ahead.
-                constexpr int DEPTH = 3, RING = 4, NSTEP = TPP * NPG;
-                uint4 fa[2][4], fb[RING];
-                auto load_a = [&](int j, uint4* fa_) {
+                // A phase is KWP kernel COLUMNS kw (one for 128-channel tiles, all three for 64-channel ones).  Inside a column
+                // the wave walks its HR = RW + 2 halo rows: the B fragment of (halo row hr, 16-pixel half cc) is read from
+                // LDS ONCE and multiplied with the weights of every kernel row kh that maps it to one of the wave's output
+                // rows (rr = hr - kh), so a fragment feeds up to 12 MFMAs instead of 4 and the halo is read 1.5-2x less
+                // often than tap by tap.  (Tap by tap the LDS reads of a 128-channel tile were 2,300 of the 3,072 cycles a
+                // phase's MFMAs take: the kernel was as much LDS-bound as MFMA-bound.)  The A fragments of the column's
+                // three taps stay in registers (12 x 4 VGPRs); B fragments run DEPTH steps ahead in a small ring.
+                constexpr int HR = RW + 2, KWP = TPP / 3, DEPTH = 2, RING = 3, NSTEP = KWP * HR * 2;
+                uint4 fa[3][4], fb[RING];
+                auto load_a = [&](int kwi, int kh) {
+                    const int j = (KWP == 1) ? kh : kh * 3 + kwi;          // tap slot inside the phase's weight image
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) fa_[ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
+                    for (int ct = 0; ct < 4; ++ct) fa[kh][ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
                 };
                 auto load_b = [&](int step) {
-                    const int tap = ph * TPP + step / NPG, pg = step % NPG;
-                    return *(const uint4*)(hb + b_base[tap % 3][pg & 1] + ((pg >> 1) + tap / 3) * (HP * 64));
+                    const int kw = ph * KWP + step / (HR * 2), hr = (step >> 1) % HR, cc = step & 1;
+                    return *(const uint4*)(hb + b_base[kw][cc] + hr * (HP * 64));
                 };
-                load_a(0, fa[0]);
+                load_a(0, 0);
 #pragma unroll
                 for (int s0 = 0; s0 < DEPTH; ++s0) fb[s0 % RING] = load_b(s0);
                 auto steps = [&](auto first_half) {
@@ -354,13 +373,29 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                     constexpr int S1 = decltype(first_half)::value ? NSTEP / 2 : NSTEP;
 #pragma unroll
                     for (int st = S0; st < S1; ++st) {
-                        const int kw = st / NPG, pg = st % NPG;      // kw: tap slot inside the phase
+                        const int kwi = st / (HR * 2), hr = (st >> 1) % HR, cc = st & 1;
                         if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
-                        if (pg == NPG / 2 && kw + 1 < TPP) load_a(kw + 1, fa[(kw + 1) & 1]);
+                        // A fragments: a column's kh = 1, 2 taps follow its first steps; the next column's taps are
+                        // requested as soon as the registers they replace have seen their last MFMA
+                        if (kwi == 0 && hr == 0) load_a(0, 1 + cc);
+                        if (cc == 0 && kwi + 1 < KWP && hr == RW) load_a(kwi + 1, 0);
+                        if (cc == 0 && kwi + 1 < KWP && hr == RW + 1) load_a(kwi + 1, 1);
+                        if (cc == 0 && kwi > 0 && hr == 0) load_a(kwi, 2);
 #pragma unroll
-                        for (int ct = 0; ct < 4; ++ct)
-                            acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fa[kw & 1][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+                        for (int kh = 0; kh < 3; ++kh) {
+                            const int rr = hr - kh;
+                            if (rr < 0 || rr >= RW) continue;
+                            const int pg = rr * 2 + cc;
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) {
+#ifdef CV2_X_NOMFMA
+                                asm volatile("" :: "v"(__builtin_bit_cast(bf16x8, fa[kh][ct])), "v"(__builtin_bit_cast(bf16x8, fb[st % RING])));
+#else
+                                acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(bf16x8, fa[kh][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+#endif
+                            }
+                        }
                         __builtin_amdgcn_sched_barrier(0);      // keep the fragment requests DEPTH steps ahead of their MFMAs
                     }
                 };
@@ -378,7 +413,9 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                     wait_landed(need);
                 }
                 STAMP(3);
+#ifndef CV2_X_NOBAR
                 __syncthreads();                        // everyone's pieces; and the stages just read are free
+#endif
                 STAMP(4);
                 if (late) late_ph = ph;
                 else if (NPH == 1 && c + 1 == nchunks) { push_w(); h_owed = true; }     // halo after the epilogue
@@ -547,7 +584,18 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             }
             }
         };
+#ifdef CV2_X_NOEPI
+        {   // timing experiment: the accumulators stay live, nothing is stored
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NPG; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (t == 1234.5f) *(float*)a.y = t;
+        }
+#else
         epilogue(std::integral_constant<bool, fast>{});
+#endif
         if (h_owed) { push_h(); h_owed = false; }
         if (DEFER && do_stats && !last_tile) {
             // nothing to write: this tile's sums ride in the workgroup's one statistics row (written on its last tile)
@@ -609,6 +657,10 @@ int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int cspl
 //  * 256-thread workgroups on 8x32-pixel tiles, two per CU, for the HBM-bound 64-channel layers (one workgroup's store
 //    burst under the other's MFMAs): correct, 6-12 % SLOWER (64->64 @512^2 forward 0.86 vs 0.78 ms).  The weights are
 //    re-streamed per tile, so halving the tile doubles the LDS-DMA instructions per MFMA (29 vs 19 per wave and tile);
+//  * producer scheme with the refill SPREAD over the phase (the barrier only plans it; one or two requests per MFMA step
+//    instead of one burst while the partner has the matrix pipe): correct, 4-5 % SLOWER on every 128-channel-tile launch
+//    (256->256 @128^2 forward 0.527 -> 0.547 ms): a request issued between a wave's own MFMAs stalls that wave's MFMA
+//    stream for longer than the burst costs;
 //  * output channels permuted in the weight image so that a lane's accumulators are two 8-channel runs of its pixel and
 //    the epilogue stores 2 x 16 bytes per lane straight from registers (no LDS transposition): correct, 0-4 % SLOWER --
 //    64-byte runs per pixel and instruction cost more at the memory side than the whole 128-byte lines of the transposed

@@ -63,8 +63,15 @@ struct Wg2Cfg {
 // layer): the DMA is one buffer_load ... lds per piece with a wave-uniform descriptor (tile origin) and
 // per-lane offsets fixed for the kernel's life; image borders use the out-of-range offset (hardware
 // writes zeros).  GEN = true: every bound checked per lane, zero block as the padded source.
-template <int KH, int KW, int SH, int WT, int TH, bool GEN>
-__global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan, FastDiv d_tw, FastDiv d_th) {
+// SPEC = true (fast path only): SPECIALISED REQUEST WAVES.  The workgroup has 12 waves, three per SIMD: waves 0-7 are the
+// 2 x 4 grid of matrix waves and never touch global memory until they store; waves 8-11 do nothing but request tiles
+// (a quarter of the pieces each), wait for them and meet the others at the tile barrier.  A request costs its wave
+// 60-180 cycles of issue (it waits for the memory pipeline to take the one before); spent by a matrix wave, as in the
+// 8-wave form, those cycles are MFMA cycles (the loop without its requests ran 1.5x faster); spent by a wave that has
+// nothing else to do they are free.  Needs the kernel to fit 168 registers (three waves per SIMD).
+template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan, FastDiv d_tw, FastDiv d_th) {
+    static_assert(!SPEC || !GEN, "request waves use the fast DMA plan");
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     constexpr int REC = C::REC, SLOTS = C::SLOTS, RPP = C::RPP, HWD = C::HWD, NT = C::NT, CT = C::CT;
 
@@ -79,7 +86,10 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     const int lblock = xcd_block_id();
     const int chan = lblock % nchan, split = lblock / nchan;
     const int co0 = (chan / nchan_ci) * CT, ci0 = (chan % nchan_ci) * CT;
-    const int wco = (wave >> 2) * (16 * WM), wci = (wave & 3) * (16 * WN);
+    const int wco = ((wave >> 2) & 1) * (16 * WM), wci = (wave & 3) * (16 * WN);
+    constexpr int NREQ = SPEC ? 4 : 8;                       // waves that request tiles
+    const bool requester = !SPEC || wave >= 8;
+    const int rw = SPEC ? (wave & 3) : wave;                 // index among the requesting waves
 
     f32x4 acc[NT][WM][WN];
 #pragma unroll
@@ -118,19 +128,20 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
 
     // ---- fast DMA plan -------------------------------------------------------------------------------
-    constexpr int DZ_PW = (C::DZ_PIECES + 7) / 8, X_PW = (C::X_PIECES + 7) / 8;
+    constexpr int DZ_PW = (C::DZ_PIECES + NREQ - 1) / NREQ, X_PW = (C::X_PIECES + NREQ - 1) / NREQ;
+    static_assert(X_PW <= 32, "piece mask is one word");
     unsigned dz_l[DZ_PW], x_l[X_PW];
-    if constexpr (!GEN) {
+    if (!GEN && requester) {
         const int rl = lane / SLOTS, s = lane % SLOTS;
 #pragma unroll
         for (int i = 0; i < DZ_PW; ++i) {
-            const int R = (wave + 8 * i) * RPP + rl;
+            const int R = (rw + NREQ * i) * RPP + rl;
             const int r = R >> 5, c = R & 31;
             dz_l[i] = (unsigned)((r * a.Wout + c) * a.lddz + (s ^ (swz_bytes<REC>(c) >> 4)) * 8) * 2u;
         }
 #pragma unroll
         for (int i = 0; i < X_PW; ++i) {
-            const int R = (wave + 8 * i) * RPP + rl;
+            const int R = (rw + NREQ * i) * RPP + rl;
             const int hr = R / HWD, hc = R - hr * HWD;
             x_l[i] = R < C::X_REC ? (unsigned)((hr * a.Win + hc) * a.ldx + (s ^ (swz_bytes<REC>(hc) >> 4)) * 8) * 2u : LDS_DMA_OOB;
         }
@@ -149,20 +160,20 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             mask = 0;
 #pragma unroll
             for (int i = 0; i < X_PW; ++i) {
-                const int R = (wave + 8 * i) * RPP + lane_ / SLOTS;
+                const int R = (rw + NREQ * i) * RPP + lane_ / SLOTS;
                 const int hr = R / HWD, hc = R - hr * HWD;
                 if ((unsigned)(row0 + hr) < (unsigned)a.Hin && (unsigned)(col0 + hc) < (unsigned)a.Win) mask |= 1u << i;
             }
         }
 #pragma unroll
         for (int i = 0; i < DZ_PW; ++i) {
-            const int piece = wave + 8 * i;
+            const int piece = rw + NREQ * i;
             if (piece < C::DZ_PIECES)
                 lds_dma16_buf(rdz, dz_l[i], __builtin_amdgcn_readfirstlane(smem_base + stage_off + piece * 1024));
         }
 #pragma unroll
         for (int i = 0; i < X_PW; ++i) {
-            const int piece = wave + 8 * i;
+            const int piece = rw + NREQ * i;
             if (piece < C::X_PIECES)
                 lds_dma16_buf(rx, ((mask >> i) & 1u) ? x_l[i] : LDS_DMA_OOB,
                               __builtin_amdgcn_readfirstlane(smem_base + stage_off + C::DZ_BYTES + piece * 1024));
@@ -209,13 +220,27 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
     };
 
     auto issue = [&](int tile, int stage_off) {
+#ifdef CV2_X_NODMA
+        return;          // timing experiment (wrong results): the loop without its requests
+#endif
         if constexpr (GEN) issue_gen(tile, stage_off); else issue_fast(tile, stage_off);
     };
-    if (t_begin < t_end) issue(t_begin, 0);
+    if (t_begin < t_end && requester) issue(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     int cur = 0;
+    if (SPEC && requester) {
+        // request wave: tile t+1 goes out as soon as the barrier has freed its stage; the barrier that ends tile t
+        // says both "t+1 has landed" (these waves wait before they arrive) and "nobody reads stage cur any more"
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            if (tile + 1 < t_end) issue(tile + 1, (cur ^ 1) * C::STAGE);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
+        }
+        return;
+    }
     for (int tile = t_begin; tile < t_end; ++tile) {
         const bool more = tile + 1 < t_end;
         const char* img = smem + cur * C::STAGE;
@@ -238,7 +263,9 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             // of their three halo rows.  Keep a ring of four halo rows in registers and read only the new one
             // per K-step (3 fragments instead of 9: the LDS read traffic of the loop drops from 22 to 10
             // transposed reads per 18 MFMAs).
-            uint4 hf[4][KW][WN];
+            // The ring holds THREE rows: row r's slot is free once the kh = 0 taps of step r have been issued, and the
+            // row the step after next needs (r + 3) is requested into it right there, under the step's other 12 MFMAs.
+            uint4 hf[3][KW][WN];
             auto load_h = [&](int row, uint4 (*dst)[WN]) {
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw)
@@ -249,20 +276,23 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             load_h(0, hf[0]); load_h(1, hf[1]); load_h(2, hf[2]);
 #pragma unroll
             for (int r = 0; r < TH; ++r) {
-                if (r + 1 < TH) {
-                    load_a(r + 1, fa[(r + 1) & 1]);
-                    load_h(r + 3, hf[(r + 3) & 3]);
-                }
-                if (more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
+                if (r + 1 < TH) load_a(r + 1, fa[(r + 1) & 1]);
+                if (!SPEC && more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
 #pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2)
+                for (int t2 = 0; t2 < NT; ++t2) {
 #pragma unroll
                     for (int i = 0; i < WM; ++i)
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
                             acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, hf[(r + t2 / KW) & 3][t2 % KW][j]),
+                                __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, hf[(r + t2 / KW) % 3][t2 % KW][j]),
                                 acc[t2][i][j], 0, 0, 0);
+                    if (t2 == KW - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (r + 1 < TH) load_h(r + 3, hf[r % 3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
             }
         } else {
         uint4 fb[2][NT][WN];
@@ -277,7 +307,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             }
             // waves 0-3 and 4-7 issue the next tile's DMA one K-step apart, so on every SIMD one wave
             // does address arithmetic while its partner feeds the matrix pipe
-            if (more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
+            if (!SPEC && more && r == (wave >> 2)) issue(tile + 1, (cur ^ 1) * C::STAGE);
 #pragma unroll
             for (int t2 = 0; t2 < NT; ++t2)
 #pragma unroll
@@ -288,7 +318,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
                             __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, fb[r & 1][t2][j]), acc[t2][i][j], 0, 0, 0);
         }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
+        if (!SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
         __syncthreads();                                    // ... everyone's; and everyone is done reading `cur`
         cur ^= 1;
     }
@@ -310,28 +340,28 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a, int nchan
             }
 }
 
-template <int KH, int KW, int SH, int WT, int TH, bool GEN>
+template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false>
 static int launch_wgrad2g(WgradArgs a, hipStream_t stream, int nsplit) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + TH - 1) / TH; a.tiles_w = (a.Wout + 31) / 32;
     a.tiles_total = a.N * a.tiles_h * a.tiles_w;
     a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
     const int nco = (a.Cout + C::CT - 1) / C::CT, nci = (a.Cin + C::CT - 1) / C::CT;
     UNET_CHECK((unsigned long long)a.tiles_total * (unsigned)(a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN>), dim3((unsigned)(nsplit * nco * nci)), dim3(512), C::SMEM, stream,
+    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC>), dim3((unsigned)(nsplit * nco * nci)), dim3(SPEC ? 768 : 512), C::SMEM, stream,
                        a, nci, nco * nci, make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
 }
 
-template <int KH, int KW, int SH, int WT, int TH>
+template <int KH, int KW, int SH, int WT, int TH, bool SPEC = false>
 static int launch_wgrad2(const WgradArgs& a, hipStream_t stream, int nsplit) {
     constexpr int CT = 32 * WT;
     const bool gen = (a.Cout % CT) != 0 || (a.Cin % CT) != 0 || (a.Hout % TH) != 0 || (a.Wout & 31) != 0;
-    return gen ? launch_wgrad2g<KH, KW, SH, WT, TH, true>(a, stream, nsplit) : launch_wgrad2g<KH, KW, SH, WT, TH, false>(a, stream, nsplit);
+    return gen ? launch_wgrad2g<KH, KW, SH, WT, TH, true>(a, stream, nsplit) : launch_wgrad2g<KH, KW, SH, WT, TH, false, SPEC>(a, stream, nsplit);
 }
 
 // geometry of the bf16 path for (kh, kw, stride): channel tile and rows per K tile
@@ -354,14 +384,14 @@ int wgrad2_splits(int kh, int kw, int sh, int N, int Hout, int Wout, int Cin, in
 int dispatch_wgrad2(int kh, int kw, int sh, const WgradArgs& a, hipStream_t s, int nsplit) {
     if (sh == 2) {
         UNET_CHECK(kh == 2 && kw == 1, "stride-2 form is the 2x1 convT view only");
-        return launch_wgrad2<2, 1, 2, 4, 2>(a, s, nsplit);
+        return launch_wgrad2<2, 1, 2, 4, 2, true>(a, s, nsplit);
     }
-    if (kh == 3 && kw == 3) return launch_wgrad2<3, 3, 1, 2, 8>(a, s, nsplit);
-    if (kh == 1 && kw == 1) return launch_wgrad2<1, 1, 1, 2, 8>(a, s, nsplit);
-    if (kh == 3 && kw == 1) return launch_wgrad2<3, 1, 1, 2, 8>(a, s, nsplit);
-    if (kh == 1 && kw == 3) return launch_wgrad2<1, 3, 1, 2, 8>(a, s, nsplit);
-    if (kh == 5 && kw == 1) return launch_wgrad2<5, 1, 1, 2, 8>(a, s, nsplit);
-    if (kh == 1 && kw == 5) return launch_wgrad2<1, 5, 1, 2, 8>(a, s, nsplit);
+    if (kh == 3 && kw == 3) return launch_wgrad2<3, 3, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 1 && kw == 1) return launch_wgrad2<1, 1, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 3 && kw == 1) return launch_wgrad2<3, 1, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 1 && kw == 3) return launch_wgrad2<1, 3, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 5 && kw == 1) return launch_wgrad2<5, 1, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 1 && kw == 5) return launch_wgrad2<1, 5, 1, 2, 8, true>(a, s, nsplit);
     unet_set_error("unsupported wgrad kernel %dx%d stride %d", kh, kw, sh);
     return -1;
 }
