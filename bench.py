@@ -31,15 +31,30 @@ TRAIN_GFLOP_PER_IMAGE_512 = 1154.0
 
 
 class ConvTimer:
-    """HIP-event timing of every 3x3 implicit-GEMM conv launch (fwd and dgrad) on the launch stream."""
+    """HIP-event timing of every bf16 3x3 implicit-GEMM launch on the launch stream: forward and dgrad
+    (conv3x3_v2_kernel, `records`) and the weight gradient (conv_wgrad2_kernel + its split-K reduce, `wgrad_records`)."""
 
     def __init__(self):
         self.records = []          # (flops, start, end)
+        self.wgrad_records = []
 
     def install(self):
         from unet_amd import ops
         orig = ops.conv_fwd
+        orig_w = ops.conv_wgrad
         recs = self.records
+        wrecs = self.wgrad_records
+
+        def timed_w(dz, x, kh, kw, *a, **k):
+            if kh == 3 and kw == 3 and x.dt == ops.BF16 and x.C >= 64:
+                s = torch.cuda.Event(enable_timing=True)
+                e = torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = orig_w(dz, x, kh, kw, *a, **k)
+                e.record()
+                wrecs.append((2.0 * x.M * 9 * x.C * dz.C, s, e))
+                return r
+            return orig_w(dz, x, kh, kw, *a, **k)
 
         def timed(x, wpacked, bias, y, kh, kw, Cin, Cout, *a, **k):
             if kh == 3 and kw == 3 and x.dt == ops.BF16:
@@ -53,26 +68,48 @@ class ConvTimer:
             return orig(x, wpacked, bias, y, kh, kw, Cin, Cout, *a, **k)
 
         ops.conv_fwd = timed
-        self._ops, self._orig = ops, orig
+        ops.conv_wgrad = timed_w
+        self._ops, self._orig, self._orig_w = ops, orig, orig_w
 
     def remove(self):
         self._ops.conv_fwd = self._orig
+        self._ops.conv_wgrad = self._orig_w
+
+    @staticmethod
+    def _sum(records):
+        return sum(r[0] for r in records), sum(r[1].elapsed_time(r[2]) for r in records), len(records)
 
     def summary(self):
-        fl = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        n = len(self.records)
-        return fl, ms, n
+        return self._sum(self.records)
+
+    def wgrad_summary(self):
+        return self._sum(self.wgrad_records)
+
+
+PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+
+
+def lib_build_id():
+    """First 12 hex digits of the SHA-256 of the HIP library this process loads (the build the numbers belong to)."""
+    import hashlib
+    from unet_amd import _lib
+    try:
+        with open(_lib.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:12]
+    except OSError:
+        return None
 
 
 def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc cannot
-    run inside this process): tools/pmc_bench.sh -> profiles/r01_pmc_traffic.json; None if absent."""
+    """(HBM-side bytes per launch of the dominant kernel, build id of the library they were counted on) from the
+    committed PMC passes (rocprofv3 --pmc cannot run inside this process): tools/pmc_bench.sh -> PMC_TRAFFIC;
+    (None, None) if absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, PMC_TRAFFIC)) as f:
+            j = json.load(f)
+        return float(j["hbm_bytes_per_launch"]), j.get("build")
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
 def cpu_baseline(sample_images=4, size=512, iters=3):
@@ -197,10 +234,20 @@ def main():
         if not args.no_conv_timer and timer.records:
             fl, ms, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_build = pmc_traffic()
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                               "traffic_source": PMC_TRAFFIC, "traffic_build": traffic_build,
                                "kernel": "conv3x3_v2_kernel<WC,GEN> (bf16 3x3 fwd + dgrad launches)",
                                "launches": n, "avg_launch_ms": ms / n, "avg_launch_gflop": fl / n / 1e9}
+            wfl, wms, wn = timer.wgrad_summary()
+            if wn:
+                wach = wfl / (wms * 1e-3) / 1e12
+                out["roofline_wgrad"] = {"bound": "mfma", "achieved": wach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": wach / MFMA_BF16_PEAK_TFLOPS,
+                                         "kernel": "conv_wgrad2_kernel<3,3,...> + split-K reduce (bf16 3x3 weight gradient launches)",
+                                         "launches": wn, "avg_launch_ms": wms / wn}
+            out["build"] = lib_build_id()
             out["train_step_tflops"] = TRAIN_GFLOP_PER_IMAGE_512 * (args.size / 512.0) ** 2 * value / 1e3
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

@@ -133,13 +133,16 @@ int unet_fold_bn_conv(const float* w, const float* bias, const float* gamma, con
  * coefficient) on the device; grad_scale = 1 normally, 1/world when the tensors hold the all-reduced SUM of the ranks'
  * gradients (train.py:143 DDP averages them): the averaging then costs no pass of its own.  unet_adamw_step multiplies the gradients by norm_out[1] (NULL: no
  * clipping; write_grads: store the clipped gradients back as clip_grad_norm_ does) and applies
- * torch.optim.AdamW's update for step number `step` (>= 1) to every tensor. */
+ * torch.optim.AdamW's update for step number `step` (>= 1) to every tensor.  veto (may be NULL) points at a device float:
+ * if it is > 0 when the kernel runs, nothing is touched.  step_batch passes the loss kernel's illegal-label counter, so a
+ * batch on which the reference raises inside loss_fn (F.one_hot, losses/segmentation.py:9; before backward and the
+ * optimizer, utils/train_step.py:52-63) does not change weights or optimizer state here either, with no extra host sync. */
 int unet_mt_blocks(int nt, const long long* numel);
 int unet_grad_sumsq(int nt, const void* const* grads, const long long* numel, double* partials, void* stream);
 int unet_grad_norm_finalize(const double* partials, int nblocks, float max_norm, float grad_scale, float* norm_out, void* stream);
 int unet_adamw_step(int nt, void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                     const long long* numel, const float* norm_out, int write_grads, double lr, double beta1,
-                    double beta2, double eps, double weight_decay, long long step, void* stream);
+                    double beta2, double eps, double weight_decay, long long step, const float* veto, void* stream);
 int unet_cast(int dtype, int to_f32, const void* src, void* dst, long long n, void* stream);
 
 /* ---- BatchNorm2d (+ReLU) -- models/unet.py:11-12,14-15 --------------------------------------

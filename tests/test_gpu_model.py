@@ -157,8 +157,17 @@ def test_step_batch_matches_reference(dev, name, fused):
         # Adam's first update is lr*sign-like: elements whose gradient is near eps move by up to lr
         tol = 2.1e-4 if noise_bias(k) else 2e-5
         assert float((p.detach().cpu() - g["step/" + k]).abs().max()) < tol, k
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    moments = [opt.state[p]["exp_avg"].clone() for p in m.parameters()] if fused else None
     with pytest.raises(RuntimeError):          # label the reference's one_hot would raise on
         step_batch(tr, g["x"].to(dev), torch.full_like(g["y"], 255).to(dev), torch.amp.GradScaler(enabled=False), 1)
+    if fused:
+        # the reference raises inside loss_fn, before backward: the bad batch must not have moved weights or moments
+        # (the loss kernel's illegal-label counter vetoes the fused update on the device)
+        for k, p in m.named_parameters():
+            assert torch.equal(p.detach(), before[k]), k
+        for p, mo in zip(m.parameters(), moments):
+            assert torch.equal(opt.state[p]["exp_avg"], mo)
 
 
 def test_eval_mode_uses_running_stats_and_no_grad(dev):

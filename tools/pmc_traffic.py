@@ -2,8 +2,11 @@
 """Per-kernel HBM traffic from the two PMC passes of tools/pmc_bench.sh.
 rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE
 counts 64 B per 128-B request of a wide coalesced read, so it is doubled; WRITE_SIZE is exact."""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
 d = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.environ.get("UNET_HIP_LIB") or os.path.join(ROOT, "unet_amd", "libunet_hip.so"), "rb") as f:
+    BUILD = hashlib.sha256(f.read()).hexdigest()[:12]      # the same id bench.py prints as "build"
 acc = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
 for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -22,7 +25,7 @@ conv = [v for k, v in out.items() if "conv3x3_v2_kernel" in k]
 if conv:
     n = sum(c["launches"] for c in conv)
     tot = sum(c["launches"] * c["hbm_bytes_per_launch"] for c in conv)
-    json.dump({"kernel": "conv3x3_v2_kernel (all instantiations)", "launches": n, "hbm_bytes_per_launch": tot / n,
+    json.dump({"kernel": "conv3x3_v2_kernel (all instantiations)", "launches": n, "hbm_bytes_per_launch": tot / n, "build": BUILD,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; 2*FETCH_SIZE + WRITE_SIZE, KiB units",
                "per_kernel": out}, open(f"{d}/traffic.json", "w"), indent=1)
     print(f"conv3x3_v2 average HBM bytes per launch: {tot/n/1e6:.1f} MB over {n} launches")

@@ -235,7 +235,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
         // says both "t+1 has landed" (these waves wait before they arrive) and "nobody reads stage cur any more"
         for (int tile = t_begin; tile < t_end; ++tile) {
             if (tile + 1 < t_end) issue(tile + 1, (cur ^ 1) * C::STAGE);
+#ifndef CV2_X_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __syncthreads();
             cur ^= 1;
         }

@@ -100,7 +100,12 @@ __device__ __forceinline__ void adamw_elem(float& p, float& g, float& m, float& 
     p = p - k.step_size * (m / denom);
 }
 
-__global__ __launch_bounds__(256) void mt_adamw_kernel(MTAdamTable tb, const float* __restrict__ clip, int write_g, AdamScalars k) {
+// veto (may be NULL): a device float; > 0 means "this batch must not change anything" (step_batch hands the loss kernel's
+// illegal-label counter over, so a batch the reference would have raised on before backward leaves weights, moments and
+// gradients as they were, without a host sync before the optimizer)
+__global__ __launch_bounds__(256) void mt_adamw_kernel(MTAdamTable tb, const float* __restrict__ clip, int write_g, AdamScalars k,
+                                                       const float* __restrict__ veto) {
+    if (veto != nullptr && veto[0] > 0.f) return;
     const int b = blockIdx.x;
     const int t = mt_find(tb.blk_end, tb.n, b);
     const int chunk = b - (t ? tb.blk_end[t - 1] : 0);
@@ -257,7 +262,7 @@ extern "C" int unet_grad_norm_finalize(const double* partials, int nblocks, floa
 
 extern "C" int unet_adamw_step(int nt, void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                const long long* numel, const float* norm_out, int write_grads, double lr, double beta1,
-                               double beta2, double eps, double weight_decay, long long step, void* stream) {
+                               double beta2, double eps, double weight_decay, long long step, const float* veto, void* stream) {
     UNET_CHECK(nt >= 0 && (nt == 0 || (params && grads && exp_avg && exp_avg_sq && numel)), "adamw_step: null argument");
     UNET_CHECK(step >= 1, "adamw_step: step must be >= 1 (got %lld)", step);
     UNET_CHECK(beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && lr >= 0, "adamw_step: bad hyper-parameters");
@@ -283,7 +288,7 @@ extern "C" int unet_adamw_step(int nt, void* const* params, void* const* grads, 
             tb.m[tb.n] = (float*)exp_avg[i0]; tb.v[tb.n] = (float*)exp_avg_sq[i0]; ++tb.n;
         }
         if (tb.n == 0) continue;
-        hipLaunchKernelGGL(mt_adamw_kernel, dim3(nb), dim3(256), 0, s, tb, norm_out, write_grads, k);
+        hipLaunchKernelGGL(mt_adamw_kernel, dim3(nb), dim3(256), 0, s, tb, norm_out, write_grads, k, veto);
         UNET_LAUNCH_CHECK();
     }
     return 0;

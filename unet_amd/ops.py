@@ -177,8 +177,14 @@ def grad_norm(grads, max_norm: float, partials: torch.Tensor, norm_out: torch.Te
 
 
 def adamw_step(params, grads, exp_avg, exp_avg_sq, norm_out: Optional[torch.Tensor], write_grads: bool,
-               lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int):
+               lr: float, beta1: float, beta2: float, eps: float, weight_decay: float, step: int,
+               veto: Optional[torch.Tensor] = None):
+    """veto: one fp32 device element; > 0 at kernel time turns the whole update into a no-op."""
     import ctypes
+    if veto is not None:
+        _need_cuda(veto)
+        if veto.dtype != torch.float32 or veto.numel() < 1:
+            raise UNetHipError("adamw_step: veto must be an fp32 device tensor")
     n = len(params)
     if not (len(grads) == len(exp_avg) == len(exp_avg_sq) == n):
         raise UNetHipError("adamw_step: list lengths differ")
@@ -192,7 +198,7 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, norm_out: Optional[torch.Tens
     check(lib().unet_adamw_step(n, PA(*[t.data_ptr() for t in params]), PA(*[t.data_ptr() for t in grads]),
                                 PA(*[t.data_ptr() for t in exp_avg]), PA(*[t.data_ptr() for t in exp_avg_sq]),
                                 (ctypes.c_longlong * n)(*numels), _p(norm_out), int(bool(write_grads)),
-                                float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _stream()),
+                                float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _p(veto), _stream()),
           "adamw_step")
 
 

@@ -78,20 +78,25 @@ class FusedAdamW(torch.optim.AdamW):
         return work
 
     # ------------------------------------------------------------------ API
-    def clip_and_step(self, parameters: Iterable[torch.Tensor], max_norm: float, grad_scale: float = 1.0) -> Optional[torch.Tensor]:
+    def clip_and_step(self, parameters: Iterable[torch.Tensor], max_norm: float, grad_scale: float = 1.0,
+                      veto: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """clip_grad_norm_(parameters, max_norm) followed by step(), without a host sync.
         Returns the total gradient norm (0-dim device tensor), as clip_grad_norm_ does.
         grad_scale: the .grad tensors hold 1/grad_scale times the gradients (data parallel hands over the all-reduced
         SUM with grad_scale = 1/world); norm, clipping and update are those of grad_scale*grad, and the clipped
-        gradients written back are the averaged ones."""
+        gradients written back are the averaged ones.
+        veto: one fp32 device element; if it is > 0 when the update kernel runs, parameters, moments and gradients are left
+        untouched (step_batch passes the loss kernel's illegal-label counter; only the fused path honours it)."""
         if isinstance(parameters, torch.Tensor):
             parameters = [parameters]
         self._pending_clip = ([p for p in parameters if p.grad is not None], float(max_norm), float(grad_scale))
         self._clip_norm = None
+        self._veto = veto
         try:
             self.step()
         finally:
             self._pending_clip = None
+            self._veto = None
         return self._clip_norm
 
     @torch.no_grad()
@@ -139,7 +144,8 @@ class FusedAdamW(torch.optim.AdamW):
                 self.state[p]["step"] += 1
             ops.adamw_step(plist, [p.grad for p in plist], [self.state[p]["exp_avg"] for p in plist],
                            [self.state[p]["exp_avg_sq"] for p in plist], norm_out, norm_out is not None,
-                           group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step + 1)
+                           group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step + 1,
+                           veto=getattr(self, "_veto", None))
             # the kernels write through raw pointers: tell autograd (and the engines' packed-weight caches)
             touched = plist + [self.state[p]["exp_avg"] for p in plist] + [self.state[p]["exp_avg_sq"] for p in plist]
             if norm_out is not None:

@@ -8,7 +8,9 @@ Differences: autocast selects the bf16 HIP kernels (the reference's fp16 autocas
 with `unet_amd.optim.FusedAdamW` (what `get_optim("adamw")` builds) and a disabled GradScaler the
 clip + optimizer tail is the fused multi-tensor path;
 the one host sync that fetches `main_loss` also carries the loss kernel's illegal-label counter, so a
-label the reference would have raised on still raises here.
+label the reference would have raised on still raises here -- at the end of the step instead of inside loss_fn; with the
+fused optimizer tail the same counter vetoes the update on the device, so the bad batch changes neither weights nor
+optimizer moments (as in the reference, where the raise comes before backward).
 """
 from contextlib import nullcontext
 from typing import Any, Dict, Tuple
@@ -52,11 +54,16 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
         grad_scale = sync(average=not use_fused) or 1.0
 
     if use_fused:
-        # unet_amd.optim.FusedAdamW: norm -> clip -> AdamW in two multi-tensor passes, no host sync
+        # unet_amd.optim.FusedAdamW: norm -> clip -> AdamW in two multi-tensor passes, no host sync.  The loss kernel's
+        # illegal-label counter rides along as a veto: a batch the reference would have raised on inside loss_fn (before
+        # backward) leaves weights and optimizer state untouched here as well; the error itself is raised below.
+        status = getattr(main_loss, "_unet_status", None)
+        kw = {}
         if grad_scale != 1.0:
-            fused(trainer.model.parameters(), trainer.grad_clip, grad_scale=grad_scale)
-        else:
-            fused(trainer.model.parameters(), trainer.grad_clip)
+            kw["grad_scale"] = grad_scale
+        if status is not None and status.dtype == torch.float32 and status.numel() >= 4:
+            kw["veto"] = status[3:4]
+        fused(trainer.model.parameters(), trainer.grad_clip, **kw)
     else:
         if trainer.grad_clip > 0:
             scaler.unscale_(trainer.optimizer)
