@@ -19,6 +19,7 @@
 #include "conv_args.h"
 #include "lds_dma.h"
 #include <type_traits>
+#include <cstdlib>
 
 
 template <int WC>
@@ -60,8 +61,11 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // GEN = false: the specialised kernel of the U-Net shapes (channel counts multiples of the tile, output
 // a whole number of 16x32 tiles, plain store, split point on a 64-channel boundary); GEN = true: the
 // same pipeline with every bound checked per lane and the accumulate / ReLU / arbitrary-split stores.
-template <int WC, bool GEN, bool DST = false>
-__global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
+// SPEC = true (64-channel tiles of the specialised kernel, no deferred statistics): SPECIALISED REQUEST WAVES, as in
+// conv_wgrad2.hip.  The workgroup has 12 waves, three per SIMD: waves 0-7 are the matrix waves, waves 8-11 issue every
+// LDS-DMA request (19-20 pieces per chunk each), wait for them and meet the others at the barriers.
+template <int WC, bool GEN, bool DST = false, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC>;
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
@@ -106,10 +110,12 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     // while the producer issues, and the producer has it while the partner waits at the next barrier: the two
     // waves of a SIMD run in anti-phase by construction instead of stalling on DMA issue side by side.
     constexpr bool ASYM = WC == 2;
-    constexpr int NPROD = ASYM ? 4 : 8;                       // waves that issue DMA
+    static_assert(!SPEC || (WC == 1 && !GEN && !DST), "request waves: 64-channel tiles of the specialised kernel");
+    constexpr int NPROD = (ASYM || SPEC) ? 4 : 8;             // waves that issue DMA
     constexpr int HPW = C::H_PIECES / NPROD;                  // halo pieces per producer wave
     static_assert(C::H_PIECES % NPROD == 0, "halo pieces must divide among the producer waves");
-    const bool producer = !ASYM || wave < 4;
+    const bool producer = SPEC ? wave >= 8 : (!ASYM || wave < 4);
+    const int pidx = SPEC ? (wave & 3) : wave;                // index among the waves that issue DMA
     const int dl = lane >> 2, ds = lane & 3;       // record within the piece, 16-byte slot
     const int wq = ds ^ swz64(dl);                 // weight source chunk (record index % 16 == dl)
     const unsigned woff = (unsigned)(dl * a.Cin + wq * 8) * 2u;
@@ -120,9 +126,10 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
         return r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + ((lane_ & 3) ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
     };
-    unsigned hoff[5];
+    constexpr int HREG = ASYM ? 1 : HPW;                      // symmetric: 5 per lane; request waves: 10 (no accumulators there)
+    unsigned hoff[HREG];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) hoff[i] = ASYM ? 0u : h_off_calc(wave + 8 * i, lane);
+    for (int i = 0; i < HREG; ++i) hoff[i] = (ASYM || !producer) ? 0u : h_off_calc(pidx + NPROD * i, lane);
     // Producer scheme: 10 offsets per lane do not fit the register budget, and recomputing them per piece costs ~15 VALU
     // instructions that have to squeeze between the SIMD partner's MFMAs (an MFMA holds the vector issue for 8 of its 16
     // cycles): the in-kernel trace showed 1,700 cycles of refill per phase for 9-10 pieces.  They are computed once into
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     unsigned* hoff_lds = (unsigned*)(smem + C::OFF_HOFF) + (ASYM ? (wave & 3) * HPW * 64 : 0);
     if (ASYM && producer) {
 #pragma unroll
-        for (int i = 0; i < HPW; ++i) hoff_lds[i * 64 + lane] = h_off_calc(wave + NPROD * i, lane);
+        for (int i = 0; i < HPW; ++i) hoff_lds[i * 64 + lane] = h_off_calc(pidx + NPROD * i, lane);
     }
     constexpr bool generic = GEN;
     const char* xg = (const char*)((const __bf16*)a.x + a.xoff);
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         asm volatile("" : "+v"(lane_));
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
-            const int r = (wave + NPROD * i) * 16 + (lane_ >> 2);
+            const int r = (pidx + NPROD * i) * 16 + (lane_ >> 2);
             const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
             if ((unsigned)(r0 + hr) < (unsigned)a.Hin && (unsigned)(c0 + hc) < (unsigned)a.Win) m |= 1u << i;
         }
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         return 1;
     };
     auto issue_w_piece = [&](const Tile& t, int c, int ph, int wstage, int i) {
-        const int p = wave + NPROD * i;
+        const int p = pidx + NPROD * i;
         if (p >= C::W_PIECES) return 0;
         const int r0 = p * 16;
         const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #ifdef CV2_X_NODMA
         return cnt;
 #endif
-        if (c == 0 && ph == 0 && a.bias != nullptr && wave == 0) cnt += issue_bias(t, bslot);
+        if (c == 0 && ph == 0 && a.bias != nullptr && pidx == 0) cnt += issue_bias(t, bslot);
         if (bias_only) return cnt;
 #pragma unroll
         for (int i = 0; i < WPW; ++i) cnt += issue_w_piece(t, c, ph, wstage, i);
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
         return make_rsrc(xg + offu, LDS_DMA_RECORDS);
     };
     auto issue_h_piece = [&](const i32x4_t rsrc, int c, int hstage, unsigned mask, int i, unsigned off) {
-        const int piece = wave + NPROD * i;
+        const int piece = pidx + NPROD * i;
         unsigned v = ((mask >> i) & 1u) ? off : LDS_DMA_OOB;
         if (generic) {
             int lane_ = lane;
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
             for (int i = 0; i < HPW; ++i) ho[i] = hoff_lds[i * 64 + lane];
         }
 #pragma unroll
-        for (int i = 0; i < HPW; ++i) issue_h_piece(rsrc, c, hstage, mask, i, ASYM ? ho[i % (ASYM ? HPW : 1)] : hoff[i % 5]);
+        for (int i = 0; i < HPW; ++i) issue_h_piece(rsrc, c, hstage, mask, i, ASYM ? ho[i % (ASYM ? HPW : 1)] : hoff[i % HREG]);
         return HPW;
     };
 
@@ -311,12 +318,36 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    if constexpr (SPEC) {
+        if (producer) {
+            // ---- request waves (one-phase chunks): after the barrier that ends chunk k they request chunk k+2 into the
+            // stages just freed, then wait for chunk k+1 and arrive at the next barrier.  At a tile's end the matrix
+            // waves transpose their output through the halo stage just read, so that stage's refill waits for the
+            // barrier behind the epilogue (the statistics' first barrier, or one of its own).
+            int ws_r = 0, hs_r = 0;
+            for (int t_i = lblock; t_i < total_tiles; t_i += (int)gridDim.x) {
+                for (int c = 0; c < nchunks; ++c) {
+                    const int need = max(ws_r ? w_mark0 : w_mark1, hs_r ? h_mark0 : h_mark1);
+                    wait_landed(need);
+                    __syncthreads();
+                    push_w();
+                    if (c + 1 < nchunks) push_h();
+                    ws_r ^= 1; hs_r ^= 1;
+                }
+                __syncthreads();
+                push_h();
+                if (a.stats != nullptr) __syncthreads();
+            }
+            return;
+        }
+    }
+
     int tile_i = lblock, tseq = 0;
     Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
     // STAGGER (symmetric scheme, 64-channel tiles): waves 0-3 refill right after the barrier, their SIMD partners
     // (waves 4-7) in the middle of the next phase's MFMAs.
-    const bool late = !ASYM && wave >= 4;
+    const bool late = !ASYM && !SPEC && wave >= 4;
     int late_ph = -1;          // the refill waves 4-7 still owe (-1: none)
     bool h_owed = false;       // waves 0-3, one-phase chunks: the halo request held back until after the epilogue
     // DEFERRED STATISTICS (64-channel tiles of the specialised kernel: one channel block, so every tile of this
@@ -417,9 +448,11 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 __syncthreads();                        // everyone's pieces; and the stages just read are free
 #endif
                 STAMP(4);
-                if (late) late_ph = ph;
-                else if (NPH == 1 && c + 1 == nchunks) { push_w(); h_owed = true; }     // halo after the epilogue
-                else refill(ph);
+                if constexpr (!SPEC) {
+                    if (late) late_ph = ph;
+                    else if (NPH == 1 && c + 1 == nchunks) { push_w(); h_owed = true; }     // halo after the epilogue
+                    else refill(ph);
+                }
                 ws ^= 1;
                 STAMP(5);
             }
@@ -610,6 +643,8 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
                 if (cur.cb * BCO + ch < a.Cout) a.stats[((size_t)row * a.Cout + cur.cb * BCO + ch) * 2 + k] = s;
             }
             __syncthreads();
+        } else if (SPEC) {
+            __syncthreads();            // the request waves may refill the halo stage the epilogue borrowed
         }
         STAMP(6);
         tile_i += gridDim.x; tseq ^= 1;
@@ -621,18 +656,18 @@ __global__ __launch_bounds__(512) void conv3x3_v2_kernel(ConvArgs a, int nco, in
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC>;
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST>), dim3((unsigned)grid), dim3(512), C::SMEM, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -670,7 +705,11 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
     if (gen) return launch_conv2<1, true>(a, s);
     // deferred statistics put a workgroup's sums (over tiles of several images) into one row: not for flags bit 2
-    // (per-tile rows grouped per image, what GroupNorm's finalize reads); conv2_rows() tells the host the row count
+    // (per-tile rows grouped per image, what GroupNorm's finalize reads); conv2_rows() tells the host the row count.
+    // Everything else on 64-channel tiles (the dgrad launches, GroupNorm forwards) runs with request waves: 64->64 @512^2
+    // dgrad 0.594 -> 0.554 ms on one box.  (The same kernel on the 128...1024-channel layers, 64 output channels per
+    // workgroup, is 2-4 % slower than the 128-channel-tile kernel: 1.35x the DMA bytes per MFMA; with the deferred
+    // statistics' 32 extra registers it does not fit three waves per SIMD.)
     return (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit)) ? launch_conv2<1, false, true>(a, s)
-                                                                                                 : launch_conv2<1, false>(a, s);
+                                                                                                 : launch_conv2<1, false, false, true>(a, s);
 }
