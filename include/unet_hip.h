@@ -275,6 +275,21 @@ int unet_fold_asymm_std(int k, int O, int I, const float* w_sq, const float* w_v
 int unet_fold_embed_add(int K, int k, int O, int I, float* target_w, const float* src_w, float* target_b,
                         const float* src_b, void* stream);
 
+/* ---- data parallel over RCCL -- train.py:33 (init_process_group "nccl"), :139-144 (DDP wrap) ---------------------
+ * For hosts without torch.distributed (the Python mirror, unet_amd/parallel.py, uses torch's RCCL backend instead).
+ * One process per GPU, that GPU current.  unet_comm_unique_id fills 128 bytes on ONE rank; the host hands them to every
+ * rank (its own channel: file, socket, MPI); unet_comm_init joins the communicator and returns an opaque handle the
+ * CALLER owns (unet_comm_destroy).  unet_allreduce_bucket sums `count` elements of dtype UNET_F32 / UNET_BF16 in place
+ * across the ranks on `stream` (DDP's per-bucket ncclAllReduce; the 1/world of the average is folded into
+ * unet_grad_norm_finalize's grad_scale, so there is no divide pass); unet_broadcast copies root's buffer to every rank
+ * (parameters at wrap time, BatchNorm buffers before each training forward: DDP's broadcast_buffers=True).
+ * RCCL is dlopen'ed on first use; the calls fail with a message if it is absent. */
+int unet_comm_unique_id(void* id128);
+int unet_comm_init(void** comm, int world, int rank, const void* id128);
+int unet_comm_destroy(void* comm);
+int unet_allreduce_bucket(void* comm, void* buf, long long count, int dtype, void* stream);
+int unet_broadcast(void* comm, void* buf, long long count, int dtype, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,37 @@ def test_world_factor_folded_into_clip_coefficient(dev, world):
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
     for a, b in zip(g1, g2):                     # the clipped AVERAGED gradients are what is left in p.grad
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+
+
+def test_c_abi_rccl_entry_points_one_rank(dev):
+    """The RCCL entry points of the C ABI (unet_comm_* / unet_allreduce_bucket / unet_broadcast: what a host without
+    torch.distributed uses for train.py:139-144), one rank, in a fresh process (a communicator of its own next to the other
+    tests' process group is not something a real host would do): the sum over one rank and the broadcast from rank 0 leave the
+    buffers as they were, for fp32 and bf16, including a count that is not a multiple of anything."""
+    code = r'''
+import ctypes, sys, torch
+sys.path.insert(0, %r)
+from unet_amd._lib import lib, check
+L = lib()
+torch.cuda.set_device(0)
+ident = ctypes.create_string_buffer(128)
+check(L.unet_comm_unique_id(ident), "unique_id")
+comm = ctypes.c_void_p()
+check(L.unet_comm_init(ctypes.byref(comm), 1, 0, ident), "comm_init")
+s = torch.cuda.current_stream().cuda_stream
+for dt, code_ in ((torch.float32, 0), (torch.bfloat16, 1)):
+    x = torch.randn(1000003, device="cuda").to(dt)
+    ref = x.clone()
+    check(L.unet_allreduce_bucket(comm, x.data_ptr(), x.numel(), code_, s), "allreduce")
+    check(L.unet_broadcast(comm, x.data_ptr(), x.numel(), code_, 0, s), "broadcast")
+    torch.cuda.synchronize()
+    assert torch.equal(x, ref), dt
+assert L.unet_allreduce_bucket(comm, None, 5, 0, s) != 0 and b"bad arguments" in L.unet_last_error()
+assert L.unet_allreduce_bucket(comm, x.data_ptr(), 5, 7, s) != 0
+check(L.unet_comm_destroy(comm), "destroy")
+print("RCCL C ABI OK")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-u", "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=170)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0 and "RCCL C ABI OK" in r.stdout, r.stdout[-3000:]
