@@ -22,19 +22,21 @@
 #include <cstdlib>
 
 
-template <int WC>
+template <int WC, int KS = 3>
 struct Cv2Cfg {
+    static_assert(KS == 3 || (KS == 5 && WC == 1), "3x3, or 5x5 on 64-channel tiles");
     static constexpr int BCO = 64 * WC;            // output channels per workgroup
     static constexpr int NWR = 8 / WC;             // wave row groups
     static constexpr int TH = 16, TW = 32;
     static constexpr int RW = TH / NWR;            // tile rows per wave (4 or 2)
     static constexpr int NPG = RW * 2;             // 16-pixel groups per wave
-    static constexpr int HP = 34;                  // halo row pitch (records)
-    static constexpr int HREC = (TH + 2) * HP;     // 612 records
-    static constexpr int H_PIECES = 40;            // 16 records per 1-KiB piece, padded to 5 per wave
+    static constexpr int HP = TW + KS - 1;         // halo row pitch (records): 34 / 36
+    static constexpr int HREC = (TH + KS - 1) * HP;   // 612 / 720 records
+    static constexpr int H_PIECES = (HREC + 127) / 128 * 8;      // 16 records per 1-KiB piece, padded to a multiple of 8: 40 / 48
     static constexpr int H_BYTES = H_PIECES * 1024;
-    static constexpr int TPP = (WC == 2) ? 3 : 9;  // taps per phase: one kernel column (kw); the whole kernel for 64-channel tiles
-    static constexpr int NPH = 9 / TPP;            // phases per 32-channel chunk
+    // taps per phase: one kernel column (kw) for 128-channel tiles and for 5x5; the whole 3x3 kernel for 64-channel tiles
+    static constexpr int TPP = (WC == 2 || KS == 5) ? KS : 9;
+    static constexpr int NPH = KS * KS / TPP;      // phases per 32-channel chunk
     static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
@@ -42,7 +44,8 @@ struct Cv2Cfg {
     static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
     // producer scheme (WC == 2): the per-lane source offsets of each producer wave's 10 halo pieces, [wave][piece][lane]
     static constexpr int OFF_HOFF = OFF_BIAS + 2 * 1024;
-    static constexpr int HOFF_BYTES = (WC == 2) ? 4 * (H_PIECES / 4) * 256 : 0;
+    static constexpr bool ASYM = WC == 2 || KS == 5;            // producer scheme: waves 0-3 issue every request
+    static constexpr int HOFF_BYTES = ASYM ? 4 * (H_PIECES / 4) * 256 : 0;
     static constexpr int SMEM = OFF_HOFF + HOFF_BYTES;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
@@ -64,9 +67,12 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // SPEC = true (64-channel tiles of the specialised kernel, no deferred statistics): SPECIALISED REQUEST WAVES, as in
 // conv_wgrad2.hip.  The workgroup has 12 waves, three per SIMD: waves 0-7 are the matrix waves, waves 8-11 issue every
 // LDS-DMA request (19-20 pieces per chunk each), wait for them and meet the others at the barriers.
-template <int WC, bool GEN, bool DST = false, bool SPEC = false>
+// KS = 5: the 5x5 convolutions of a deployed RepUNet (models/reparm_unet.py:139, kernel_sizes [3,5] folded) and of its
+// training branches, on 64-channel tiles with one kernel column (5 taps) per phase.
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KS = 3>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
-    using C = Cv2Cfg<WC>;
+    using C = Cv2Cfg<WC, KS>;
+    static_assert(KS == 3 || (!GEN && !DST && !SPEC), "5x5: the specialised kernel only");
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -89,9 +95,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // A (weights): record = tapslot*BCO + wc*64 + ct*16 + l15, k-slot g
     const int a_base = C::OFF_W + (wc * 64 + l15) * 64 + ((g ^ swz64(l15)) << 4);
     // B (halo): record = (wr*RW + rr + kh)*HP + cc*16 + l15 + kw, k-slot g
-    int b_base[3][2];
+    int b_base[KS][2];
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
+    for (int kw = 0; kw < KS; ++kw)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int col = cc * 16 + l15 + kw;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // SIMD partners (waves 4-7) never do.  After a barrier the partner therefore has the matrix pipe to itself
     // while the producer issues, and the producer has it while the partner waits at the next barrier: the two
     // waves of a SIMD run in anti-phase by construction instead of stalling on DMA issue side by side.
-    constexpr bool ASYM = WC == 2;
+    constexpr bool ASYM = C::ASYM;
     static_assert(!SPEC || (WC == 1 && !GEN && !DST), "request waves: 64-channel tiles of the specialised kernel");
     constexpr int NPROD = (ASYM || SPEC) ? 4 : 8;             // waves that issue DMA
     constexpr int HPW = C::H_PIECES / NPROD;                  // halo pieces per producer wave
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // recomputed per request for the producer scheme (10 per lane would not fit the register budget)
     auto h_off_calc = [&](int piece, int lane_) -> unsigned {
         const int r = piece * 16 + (lane_ >> 2);
-        const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
+        const int hr = r / HP, hc = r - hr * HP;
         return r < C::HREC ? (unsigned)((hr * a.Win + hc) * a.ldx + ((lane_ & 3) ^ swz64(hc)) * 8) * 2u : LDS_DMA_OOB;
     };
     constexpr int HREG = ASYM ? 1 : HPW;                      // symmetric: 5 per lane; request waves: 10 (no accumulators there)
@@ -157,13 +163,13 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     auto halo_mask = [&](const Tile& t) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         unsigned m = 0;
-        if (r0 >= 0 && r0 + C::TH + 2 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return (1u << HPW) - 1u;     // interior tile (wave-uniform)
+        if (r0 >= 0 && r0 + C::TH + KS - 1 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return (1u << HPW) - 1u;     // interior tile (wave-uniform)
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
 #pragma unroll
         for (int i = 0; i < HPW; ++i) {
             const int r = (pidx + NPROD * i) * 16 + (lane_ >> 2);
-            const int hr = (r * 241) >> 13, hc = r - hr * HP;          // r / 34 for r < 1024
+            const int hr = r / HP, hc = r - hr * HP;
             if ((unsigned)(r0 + hr) < (unsigned)a.Hin && (unsigned)(c0 + hc) < (unsigned)a.Win) m |= 1u << i;
         }
         return m;
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
         if (p >= C::W_PIECES) return 0;
         const int r0 = p * 16;
         const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
-        const int tap = (NPH == 1) ? j : j * 3 + ph;                  // a phase of a 128-channel tile is one kernel COLUMN: taps (kh = j, kw = ph)
+        const int tap = (NPH == 1) ? j : j * KS + ph;                 // a one-column phase holds taps (kh = j, kw = ph)
         const long long offu = ((long long)(tap * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
         unsigned v = woff;
         if (generic) {
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
             int lane_ = lane;
             asm volatile("" : "+v"(lane_));
             const int r = piece * 16 + (lane_ >> 2);
-            const int hr = (r * 241) >> 13, hc = r - hr * HP;
+            const int hr = r / HP, hc = r - hr * HP;
             if (c * 32 + ((lane_ & 3) ^ swz64(hc)) * 8 >= a.Cin) v = LDS_DMA_OOB;
         }
         lds_dma16_buf(rsrc, v, __builtin_amdgcn_readfirstlane(sb + C::OFF_H + hstage * C::H_BYTES + piece * 1024));
@@ -385,10 +391,11 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                 // often than tap by tap.  (Tap by tap the LDS reads of a 128-channel tile were 2,300 of the 3,072 cycles a
                 // phase's MFMAs take: the kernel was as much LDS-bound as MFMA-bound.)  The A fragments of the column's
                 // three taps stay in registers (12 x 4 VGPRs); B fragments run DEPTH steps ahead in a small ring.
-                constexpr int HR = RW + 2, KWP = TPP / 3, DEPTH = 2, RING = 3, NSTEP = KWP * HR * 2;
-                uint4 fa[3][4], fb[RING];
+                constexpr int HR = RW + KS - 1, KWP = TPP / KS, DEPTH = 2, RING = 3, NSTEP = KWP * HR * 2;
+                static_assert(KS == 3 || KWP == 1, "the cross-column A prefetch below is written for three kernel rows");
+                uint4 fa[KS][4], fb[RING];
                 auto load_a = [&](int kwi, int kh) {
-                    const int j = (KWP == 1) ? kh : kh * 3 + kwi;          // tap slot inside the phase's weight image
+                    const int j = (KWP == 1) ? kh : kh * KS + kwi;         // tap slot inside the phase's weight image
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) fa[kh][ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
                 };
@@ -408,12 +415,12 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                         if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
                         // A fragments: a column's kh = 1, 2 taps follow its first steps; the next column's taps are
                         // requested as soon as the registers they replace have seen their last MFMA
-                        if (kwi == 0 && hr == 0) load_a(0, 1 + cc);
+                        if (kwi == 0 && 1 + 2 * hr + cc < KS) load_a(0, 1 + 2 * hr + cc);      // kh = 1.. follow the first steps
                         if (cc == 0 && kwi + 1 < KWP && hr == RW) load_a(kwi + 1, 0);
                         if (cc == 0 && kwi + 1 < KWP && hr == RW + 1) load_a(kwi + 1, 1);
                         if (cc == 0 && kwi > 0 && hr == 0) load_a(kwi, 2);
 #pragma unroll
-                        for (int kh = 0; kh < 3; ++kh) {
+                        for (int kh = 0; kh < KS; ++kh) {
                             const int rr = hr - kh;
                             if (rr < 0 || rr >= RW) continue;
                             const int pg = rr * 2 + cc;
@@ -656,18 +663,18 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false, bool SPEC = false>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KS = 3>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
-    using C = Cv2Cfg<WC>;
+    using C = Cv2Cfg<WC, KS>;
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KS>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KS>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -713,3 +720,11 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     return (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit)) ? launch_conv2<1, false, true>(a, s)
                                                                                                  : launch_conv2<1, false, false, true>(a, s);
 }
+
+// 5x5 stride 1 on whole 16x32 tiles and whole 64-channel blocks: the LDS-DMA kernel (one stats row per pixel tile); everything
+// else stays on conv_igemm.hip (8x32 tiles).  unet_conv_tiles() asks the same question to size the statistics rows.
+bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
+    return (Cin & 31) == 0 && (Cout & 63) == 0 && (Hout & 15) == 0 && (Wout & 31) == 0 && (flags & 1) == 0 && (csplit & 63) == 0;
+}
+int conv5_rows(int N, int Hout, int Wout) { return N * (Hout / 16) * (Wout / 32); }
+int dispatch_conv5(const ConvArgs& a, hipStream_t s) { return launch_conv2<1, false, false, false, 5>(a, s); }

@@ -253,6 +253,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 // bf16 3x3 stride-1 path (conv_fwd2.hip)
 int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int csplit);
 int dispatch_conv2(const ConvArgs& a, hipStream_t s);
+// bf16 5x5 stride-1 path on whole tiles (conv_fwd2.hip)
+bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit);
+int conv5_rows(int N, int Hout, int Wout);
+int dispatch_conv5(const ConvArgs& a, hipStream_t s);
+static bool use_conv5(int dtype, int kh, int kw, int sh, int epi, int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
+    return dtype == UNET_BF16 && kh == 5 && kw == 5 && sh == 1 && epi == 0 && conv5_v2_ok(Cin, Cout, Hout, Wout, flags, csplit);
+}
 // bf16 ConvTranspose2d forward / dgrad on whole tiles (conv_t2.hip)
 bool convT2_fwd_ok(const ConvArgs& a);
 int convT2_fwd(const ConvArgs& a, hipStream_t s);
@@ -287,6 +294,7 @@ static int dispatch_conv(int kh, int kw, int sh, int epi, const ConvArgs& a, hip
 extern "C" int unet_conv_tiles(int dtype, int kh, int kw, int stride_h, int epi, int N, int Hout, int Wout,
                                int Cin, int Cout, int flags, int csplit) {
     if (use_conv2(dtype, kh, kw, stride_h, epi)) return conv2_rows(N, Hout, Wout, Cin, Cout, flags, csplit);
+    if (use_conv5(dtype, kh, kw, stride_h, epi, Cin, Cout, Hout, Wout, flags, csplit)) return conv5_rows(N, Hout, Wout);
     return N * ((Hout + 7) / 8) * ((Wout + 31) / 32);
 }
 
@@ -321,6 +329,10 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     if (use_conv2(dtype, kh, kw, stride_h, epi)) {
         UNET_CHECK((size_t)9 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");
         return dispatch_conv2(a, s);
+    }
+    if (use_conv5(dtype, kh, kw, stride_h, epi, Cin, Cout, Hout, Wout, flags, csplit)) {
+        UNET_CHECK((size_t)25 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");
+        return dispatch_conv5(a, s);
     }
     if (dtype == UNET_BF16 && epi == 1 && kh == 1 && kw == 1 && stride_h == 1 && convT2_fwd_ok(a)) return convT2_fwd(a, s);
     if (dtype == UNET_BF16 && epi == 0 && kh == 2 && kw == 1 && stride_h == 2 && convT2_dgrad_ok(a)) return convT2_dgrad(a, s);
