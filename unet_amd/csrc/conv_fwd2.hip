@@ -546,8 +546,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                 const size_t row_stride = (size_t)a.Wout * ld * 2, half_stride = (size_t)8 * ld * 2;
                 char* wbase = scr + (wpx >> 3) * 8192 + (wpx & 7) * 128 + (ge & 1) * 8;
                 const char* rbase = scr + rpx * 128 + ((rch ^ rpx) << 4);
-                auto pass2 = [&](auto relu_tag) {
+                auto pass2 = [&](auto relu_tag, auto nt_tag) {
                     constexpr bool RELU = decltype(relu_tag)::value;            // deployed / BN-folded inference convs
+                    constexpr bool NT = decltype(nt_tag)::value;                // streaming stores (flags bit 3, set by the launcher)
 #pragma unroll
                     for (int pg = 0; pg < NPG; ++pg) {
 #pragma unroll
@@ -565,11 +566,17 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             const uint4 val = *(const uint4*)(rbase + h * 8192);
-                            *(uint4*)(pp + h * half_stride) = val;
+                            if constexpr (NT) {
+                                typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+                                __builtin_nontemporal_store(u32x4_nt{val.x, val.y, val.z, val.w}, (u32x4_nt*)(pp + h * half_stride));
+                            } else {
+                                *(uint4*)(pp + h * half_stride) = val;
+                            }
                         }
                     }
                 };
-                if (a.flags & 2) pass2(std::true_type{}); else pass2(std::false_type{});
+                if (a.flags & 8) { if (a.flags & 2) pass2(std::true_type{}, std::true_type{}); else pass2(std::false_type{}, std::true_type{}); }
+                else { if (a.flags & 2) pass2(std::true_type{}, std::false_type{}); else pass2(std::false_type{}, std::false_type{}); }
             } else {
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
@@ -669,6 +676,10 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     static DynLdsOnce lds_once;
     if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KS>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
+    // STREAMING STORES for outputs far larger than the L2s (8 x 4 MiB): the store burst of one round of tiles (32 workgroups
+    // x 128 KiB per XCD) otherwise evicts the weights and halos the next round wants.  Same box: 256->256 @128^2 (268 MB
+    // out) forward -4 %, dgrad -3 %; 1024->1024 @32^2 (67 MB) +1.5 % with them, hence the threshold (nt_threshold_bytes(), 100 MiB); whole step -0.25 ms.
+    if ((size_t)a.N * a.Hout * a.Wout * a.Cout * 2 >= nt_threshold_bytes()) a.flags |= 8;
     const int nco = (a.Cout + C::BCO - 1) / C::BCO;
     const int total = a.N * a.tiles_h * a.tiles_w * nco;
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU

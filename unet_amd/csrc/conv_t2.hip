@@ -30,6 +30,7 @@ struct CT2Args {
     int lds_, soff, ldd, doff;
     int Ci, Co;
     int tiles_h, tiles_w, ntile_n, total_tiles, nk;
+    int nt;               // streaming stores
 };
 
 struct CT2Cfg {
@@ -217,7 +218,12 @@ __global__ __launch_bounds__(768) void convT2_kernel(CT2Args a, FastDiv d_n, Fas
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const uint4 val = *(const uint4*)(rbase + h * 1024);
-                    *(uint4*)(pp + h * half_stride) = val;
+                    if (a.nt) {         // streaming stores for outputs far larger than the L2s (see conv_fwd2.hip)
+                        typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(u32x4_nt{val.x, val.y, val.z, val.w}, (u32x4_nt*)(pp + h * half_stride));
+                    } else {
+                        *(uint4*)(pp + h * half_stride) = val;
+                    }
                 }
             }
         }
@@ -235,6 +241,7 @@ static int launch_convT2(CT2Args a, hipStream_t stream) {
     a.ntile_n = (DGRAD ? a.Ci : 4 * a.Co) / 128;
     a.total_tiles = a.N * a.tiles_h * a.tiles_w * a.ntile_n;
     a.nk = (DGRAD ? 4 * a.Co : a.Ci) / 32;
+    a.nt = (size_t)a.N * a.H * a.W * (DGRAD ? a.Ci : 4 * a.Co) * 2 >= nt_threshold_bytes();
     const int mx = a.ntile_n > a.tiles_w ? (a.ntile_n > a.tiles_h ? a.ntile_n : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h);
     UNET_CHECK((unsigned long long)a.total_tiles * (unsigned)mx < (1ull << 32), "tile count too large for the index arithmetic");
     const int grid = a.total_tiles < 256 ? a.total_tiles : 256;

@@ -57,3 +57,12 @@ __device__ __forceinline__ int xcd_block_id() {
     const int g = (int)gridDim.x, b = (int)blockIdx.x;
     return (g & 7) ? b : (b & 7) * (g >> 3) + (b >> 3);
 }
+
+// Outputs at least this large are written with streaming (nontemporal) stores by the persistent conv kernels: the store
+// burst of one round of tiles otherwise evicts the operands of the next from the 8 x 4 MiB of L2.  UNET_AMD_NT_MB overrides
+// the 100 MiB default (experiments).
+#include <cstdlib>
+static inline size_t nt_threshold_bytes() {
+    static const size_t v = [] { const char* e = getenv("UNET_AMD_NT_MB"); const long mb = e ? atol(e) : 100; return (size_t)(mb > 0 ? mb : 100) << 20; }();
+    return v;
+}
