@@ -275,6 +275,16 @@ int unet_fold_asymm_std(int k, int O, int I, const float* w_sq, const float* w_v
 int unet_fold_embed_add(int K, int k, int O, int I, float* target_w, const float* src_w, float* target_b,
                         const float* src_b, void* stream);
 
+/* ---- bilinear resize -- models/unet.py:56-57 ------------------------------------------------------------------
+ * F.interpolate(x, size=skip.shape[2:], mode="bilinear", align_corners=True): the branch UNet.forward takes when H or W
+ * is not divisible by 2^levels and an upsampled tensor misses its skip connection by a pixel.  NHWC channel slices
+ * (ptr, ld, off) as everywhere; x is [N,h,w,C], y is [N,H,W,C].  _bwd is the adjoint (dx = J^T dy), evaluated as a gather
+ * (deterministic).  unet_maxpool2x2_fwd/_bwd accept odd H, W with nn.MaxPool2d's floor rule for the same case. */
+int unet_resize_bilinear_fwd(int dtype, const void* x, int ldx, int xoff, int h, int w,
+                             void* y, int ldy, int yoff, int H, int W, int N, int C, void* stream);
+int unet_resize_bilinear_bwd(int dtype, const void* dy, int ldy, int yoff, int H, int W,
+                             void* dx, int ldx, int xoff, int h, int w, int N, int C, void* stream);
+
 /* ---- data parallel over RCCL -- train.py:33 (init_process_group "nccl"), :139-144 (DDP wrap) ---------------------
  * For hosts without torch.distributed (the Python mirror, unet_amd/parallel.py, uses torch's RCCL backend instead).
  * One process per GPU, that GPU current.  unet_comm_unique_id fills 128 bytes on ONE rank; the host hands them to every

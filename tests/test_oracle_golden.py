@@ -171,3 +171,32 @@ def test_step_matches_reference_step_batch(name):
         # Adam update lr*g/(|g|+eps) is noise of size <= lr: bound them by one full step instead
         noise = ".double_conv.0.bias" in k or ".double_conv.3.bias" in k
         assert (p - g["step/" + k]).abs().max() < (2.1e-4 if noise else 5e-6), k
+
+
+def test_odd_input_size_resize_branch_matches_reference():
+    """models/unet.py:56-57 and models/reparm_unet.py:209-210: F.interpolate(..., bilinear, align_corners=True) of the
+    upsampled tensor when a skip is a pixel larger (goldens from the real reference on 2x1x36x44,
+    tests/golden/make_odd_size.py)."""
+    g = load("unet_odd_36x44")
+    st = {k: v.clone() for k, v in split(g, "init/").items()}
+    params = [k for k in st if not ("running_" in k or "num_batches" in k)]
+    for k in params:
+        st[k].requires_grad_(True)
+    nb = {}
+    logits = unet_ref.unet_forward(g["x"], st, train=True, new_buffers=nb)
+    loss = loss_ref.ce_dice(logits, g["y"], 1.0, 1.0, 255)
+    loss.backward()
+    assert relerr(logits.detach(), g["logits"]) < 1e-5 and abs(float(loss) - float(g["loss"])) < 1e-6
+    for k in params:
+        if ".double_conv.0.bias" in k or ".double_conv.3.bias" in k:
+            assert (st[k].grad - g["grad/" + k]).abs().max() < 1e-6
+        else:
+            assert relerr(st[k].grad, g["grad/" + k]) < 1e-4, k
+    g = load("repunet_odd_36x44")
+    st = {k: v.clone().requires_grad_(True) for k, v in split(g, "init/").items()}
+    logits = unet_ref.repunet_forward(g["x"], st, [3], norm="group")
+    loss = loss_ref.ce_dice(logits, g["y"], 1.0, 1.0, 255)
+    loss.backward()
+    assert relerr(logits.detach(), g["logits"]) < 1e-5 and abs(float(loss) - float(g["loss"])) < 1e-6
+    for k in st:
+        assert relerr(st[k].grad, g["grad/" + k]) < 2e-4, k

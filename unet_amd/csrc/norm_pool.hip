@@ -509,6 +509,27 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// Odd H or W (nn.MaxPool2d floors): the last row / column belongs to no window, its gradient is the skip's alone.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_edge_kernel(const T* __restrict__ dskip, int lds_, int soff,
+                                                               T* __restrict__ dx, int N, int H, int W, int C) {
+    constexpr int EPV = TT<T>::EPV;
+    const int G = C / EPV;
+    const int nrow = (H & 1) ? W : 0, ncol = (W & 1) ? (H - (H & 1)) : 0;       // last row; last column without the corner
+    const long long total = (long long)N * (nrow + ncol) * G;
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total; v += (long long)gridDim.x * 256) {
+        const int cg = (int)(v % G);
+        long long p = v / G;
+        const int e = (int)(p % (nrow + ncol));
+        const int n = (int)(p / (nrow + ncol));
+        const int hh = e < nrow ? H - 1 : e - nrow, ww = e < nrow ? e : W - 1;
+        const long long pix = ((long long)n * H + hh) * W + ww;
+        uint4 g = make_uint4(0u, 0u, 0u, 0u);
+        if (dskip != nullptr) g = *(const uint4*)(dskip + pix * lds_ + soff + cg * EPV);
+        *(uint4*)(dx + pix * C + cg * EPV) = g;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 static inline int stream_grid_cap() {
     static const int v = [] { const char* e = getenv("UNET_AMD_BN_GRID"); const int g = e ? atoi(e) : 0; return g > 0 ? g : STREAM_GRID_CAP; }();
@@ -779,7 +800,7 @@ extern "C" int unet_channel_sum(int dtype, const void* x, int ldx, int xoff, lon
 extern "C" int unet_maxpool2x2_fwd(int dtype, const void* x, int ldx, int xoff, void* y, uint8_t* code,
                                    int N, int H, int W, int C, void* stream) {
     if (chan_check(dtype, C, "maxpool_fwd")) return -1;
-    UNET_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "maxpool: H and W must be even (got %dx%d)", H, W);
+    UNET_CHECK(H > 1 && W > 1, "maxpool: H and W must be at least 2 (got %dx%d)", H, W);      // odd sizes: floor, as nn.MaxPool2d(2, 2)
     UNET_CHECK(ldx % 8 == 0 && xoff % 8 == 0, "maxpool: stride/offset must be multiples of 8");
     const int epv = dtype == UNET_BF16 ? 8 : 4;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / epv);
@@ -796,7 +817,7 @@ extern "C" int unet_maxpool2x2_fwd(int dtype, const void* x, int ldx, int xoff, 
 extern "C" int unet_maxpool2x2_bwd(int dtype, const void* dy, const uint8_t* code, const void* dskip, int lds_, int soff,
                                    void* dx, int N, int H, int W, int C, void* stream) {
     if (chan_check(dtype, C, "maxpool_bwd")) return -1;
-    UNET_CHECK(H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, "maxpool: H and W must be even (got %dx%d)", H, W);
+    UNET_CHECK(H > 1 && W > 1, "maxpool: H and W must be at least 2 (got %dx%d)", H, W);
     const int epv = dtype == UNET_BF16 ? 8 : 4;
     const long long total = (long long)N * (H / 2) * (W / 2) * (C / epv);
     const int grid = grid_for(total, 256);
@@ -806,5 +827,14 @@ extern "C" int unet_maxpool2x2_bwd(int dtype, const void* dy, const uint8_t* cod
     else
         hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dy, code, (const float*)dskip, lds_, soff, (float*)dx, N, H, W, C);
     UNET_LAUNCH_CHECK();
+    if ((H | W) & 1) {
+        const int nedge = ((H & 1) ? W : 0) + ((W & 1) ? (H - (H & 1)) : 0);
+        const int ge = grid_for((long long)N * nedge * (C / epv), 256);
+        if (dtype == UNET_BF16)
+            hipLaunchKernelGGL((maxpool_bwd_edge_kernel<__bf16>), dim3(ge), dim3(256), 0, s, (const __bf16*)dskip, lds_, soff, (__bf16*)dx, N, H, W, C);
+        else
+            hipLaunchKernelGGL((maxpool_bwd_edge_kernel<float>), dim3(ge), dim3(256), 0, s, (const float*)dskip, lds_, soff, (float*)dx, N, H, W, C);
+        UNET_LAUNCH_CHECK();
+    }
     return 0;
 }

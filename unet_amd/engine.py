@@ -230,9 +230,10 @@ class UNetEngine:
         L = len(self.features)
         if Cin != self.in_channels:
             raise ops.UNetHipError(f"expected {self.in_channels} input channels, got {Cin}")
-        if H % (1 << L) or W % (1 << L):
-            # the reference falls into a bilinear-resize branch here (models/unet.py:56-57); not built
-            raise ops.UNetHipError(f"H and W must be divisible by {1 << L} (got {H}x{W})")
+        if (H >> L) < 1 or (W >> L) < 1:
+            raise ops.UNetHipError(f"input {H}x{W} is too small for {L} pooling levels")
+        # H or W not divisible by 2^levels: a level with an odd size pools with the floor rule (stand-alone kernels instead
+        # of the fused ones) and the decoder resizes the upsampled tensor to its skip's size (models/unet.py:56-57)
         dev = x.device
         self._last_dt = dt
         self.prepack(P, dt)
@@ -259,7 +260,7 @@ class UNetEngine:
             cats.append(cat)
             p = f"downs.{i}"
             skip = Act(cat, 0, f)
-            if self.fused_pool_fwd:
+            if self.fused_pool_fwd and h % 2 == 0 and w % 2 == 0:
                 _, rec = self.block_fwd(P, B, p, cur, skip, dt, train, save, x_f32=x_nhwc if i == 0 else None, pool=True)
                 cur, code = self._pooled
                 self._pooled = None
@@ -279,9 +280,16 @@ class UNetEngine:
             wt, bt = P[f"ups.{2 * j}.weight"], P[f"ups.{2 * j}.bias"]
             if save:
                 sv.up_in.append(cur)
-            # ConvTranspose2d(2f -> f, k2, s2) as GEMM + pixel shuffle into cat[..., f:2f]
-            ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), Act(cat, f, f), 1, 1,
-                         2 * f, 4 * f, epi=1)
+            if (2 * cur.H, 2 * cur.W) == (cat.shape[1], cat.shape[2]):
+                # ConvTranspose2d(2f -> f, k2, s2) as GEMM + pixel shuffle into cat[..., f:2f]
+                ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), Act(cat, f, f), 1, 1,
+                             2 * f, 4 * f, epi=1)
+            else:
+                # the skip is a pixel larger (odd size at this level): upsample into a buffer of its own, then
+                # F.interpolate(..., mode="bilinear", align_corners=True) into the concat slice (models/unet.py:56-57)
+                up = ops.dense(cur.N, 2 * cur.H, 2 * cur.W, f, dt, dev)
+                ops.conv_fwd(cur, self.packed(f"ups.{2 * j}.weight", wt, 2, dt), bt.detach(), up, 1, 1, 2 * f, 4 * f, epi=1)
+                ops.resize_bilinear(up, Act(cat, f, f))
             p = f"ups.{2 * j + 1}"
             head = None
             if j == L - 1 and fuse_out:
@@ -392,6 +400,13 @@ class UNetEngine:
             dskips[L - 1 - j] = dskip
             xin = sv.up_in[j]
             tname = f"ups.{2 * j}"
+            if (2 * xin.H, 2 * xin.W) != (dup.H, dup.W):
+                # the upsampled tensor went through the bilinear resize: its adjoint first, then the bias gradient from
+                # the small tensor (the dgrad epilogue's rows belong to the resized one)
+                dsmall = ops.dense(xin.N, 2 * xin.H, 2 * xin.W, f, dt, dev)
+                ops.resize_bilinear_bwd(dup, dsmall)
+                dup = dsmall
+                res = (dskip, dup)
             if len(res) > 2:        # [tiles][2f][sum, sum of squares] from the dgrad epilogue
                 rows = res[2]
                 ctot = rows.shape[1]
@@ -406,7 +421,7 @@ class UNetEngine:
         dcur = self.block_bwd(P, sv, "bottleneck", dcur, grads, dt)
         emit(self.block_param_names("bottleneck"))
         for i in reversed(range(L)):
-            if self.fused_pool_bwd:
+            if self.fused_pool_bwd and dskips[i].H % 2 == 0 and dskips[i].W % 2 == 0:
                 dy2 = ops.PoolGrad(dcur, sv.codes[i], dskips[i])
             else:
                 dy2 = ops.maxpool_bwd(dcur, sv.codes[i], dskips[i])

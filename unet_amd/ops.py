@@ -606,33 +606,55 @@ def rows_colsum(rows: torch.Tensor, off: int, C: int, stride: int) -> torch.Tens
 
 
 def maxpool_fwd(x: Act):
-    """-> (pooled dense Act, uint8 code tensor [N,H/2,W/2,C])."""
+    """-> (pooled dense Act, uint8 code tensor [N,H//2,W//2,C]); odd sizes floor, as nn.MaxPool2d(2, 2)."""
     x.check()
-    if x.H % 2 or x.W % 2:
-        raise UNetHipError(f"maxpool: H and W must be even, got {x.H}x{x.W}")
+    if x.H < 2 or x.W < 2:
+        raise UNetHipError(f"maxpool: H and W must be at least 2, got {x.H}x{x.W}")
     y = dense(x.N, x.H // 2, x.W // 2, x.C, x.dt, x.buf.device)
     code = torch.empty((x.N, x.H // 2, x.W // 2, x.C), dtype=torch.uint8, device=x.buf.device)
     check(lib().unet_maxpool2x2_fwd(x.dt, _p(x.buf), x.ld, x.off, _p(y.buf), _p(code), x.N, x.H, x.W, x.C, _stream()), "maxpool_fwd")
     return y, code
 
 
-def maxpool_bwd(dy: Act, code: torch.Tensor, dskip: Optional[Act]) -> Act:
-    """dx[N,H,W,C] = unpool(dy) (+ dskip)."""
+def maxpool_bwd(dy: Act, code: torch.Tensor, dskip: Optional[Act], out_hw=None) -> Act:
+    """dx[N,H,W,C] = unpool(dy) (+ dskip).  (H, W) = dskip's, else out_hw, else (2*Ho, 2*Wo); an odd H or W leaves its
+    last row / column outside every window (gradient = dskip's alone)."""
     dy.check()
     if dy.off != 0 or dy.ld != dy.C:
         raise UNetHipError("maxpool_bwd: pooled gradient must be dense")
     N, Ho, Wo, C = dy.N, dy.H, dy.W, dy.C
     if tuple(code.shape) != (N, Ho, Wo, C):
         raise UNetHipError("maxpool_bwd: code shape mismatch")
+    H, W = (dskip.H, dskip.W) if dskip is not None else (out_hw if out_hw is not None else (2 * Ho, 2 * Wo))
+    if H // 2 != Ho or W // 2 != Wo:
+        raise UNetHipError("maxpool_bwd: output size does not pool to the gradient's size")
     if dskip is not None:
         dskip.check()
-        if (dskip.N, dskip.H, dskip.W, dskip.C) != (N, 2 * Ho, 2 * Wo, C):
+        if (dskip.N, dskip.C) != (N, C):
             raise UNetHipError("maxpool_bwd: skip gradient shape mismatch")
-    dx = dense(N, 2 * Ho, 2 * Wo, C, dy.dt, dy.buf.device)
+    dx = dense(N, H, W, C, dy.dt, dy.buf.device)
     check(lib().unet_maxpool2x2_bwd(dy.dt, _p(dy.buf), _p(code), _p(dskip.buf) if dskip is not None else None,
                                     dskip.ld if dskip is not None else 0, dskip.off if dskip is not None else 0,
-                                    _p(dx.buf), N, 2 * Ho, 2 * Wo, C, _stream()), "maxpool_bwd")
+                                    _p(dx.buf), N, H, W, C, _stream()), "maxpool_bwd")
     return dx
+
+
+def resize_bilinear(x: Act, y: Act):
+    """y = F.interpolate(x, size=(y.H, y.W), mode="bilinear", align_corners=True) (models/unet.py:56-57), NHWC slices."""
+    x.check(); y.check()
+    if (x.N, x.C, x.dt) != (y.N, y.C, y.dt):
+        raise UNetHipError("resize_bilinear: batch / channel / dtype mismatch")
+    check(lib().unet_resize_bilinear_fwd(x.dt, _p(x.buf), x.ld, x.off, x.H, x.W, _p(y.buf), y.ld, y.off, y.H, y.W, x.N, x.C, _stream()),
+          "resize_bilinear_fwd")
+
+
+def resize_bilinear_bwd(dy: Act, dx: Act):
+    """dx = adjoint of resize_bilinear applied to dy (dx has the small shape)."""
+    dy.check(); dx.check()
+    if (dx.N, dx.C, dx.dt) != (dy.N, dy.C, dy.dt):
+        raise UNetHipError("resize_bilinear_bwd: batch / channel / dtype mismatch")
+    check(lib().unet_resize_bilinear_bwd(dy.dt, _p(dy.buf), dy.ld, dy.off, dy.H, dy.W, _p(dx.buf), dx.ld, dx.off, dx.H, dx.W, dx.N, dx.C,
+                                         _stream()), "resize_bilinear_bwd")
 
 
 def pool_indices_int64(code: torch.Tensor, W: int) -> torch.Tensor:
