@@ -65,37 +65,39 @@ REAL_CONV5 = [          # deployed RepUNet [3,5] -> 5x5 (models/reparm_unet.py:1
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("k", [(5, 5), (3, 1), (5, 1), (1, 3), (1, 5)])
 @pytest.mark.parametrize("shape", REAL_CONV5)
-def test_conv5x5_real_widths(dev, dt, shape):
-    """bf16: the 5x5 instantiation of the LDS-DMA kernel (one kernel column per phase); fp32: conv_igemm.  Forward with
-    statistics, forward with the deployed path's bias + ReLU epilogue, dgrad; against F.conv2d on the CPU."""
+def test_conv5x5_and_asymmetric_real_widths(dev, dt, k, shape):
+    """bf16: the 5x5 / k x 1 / 1 x k instantiations of the LDS-DMA kernel (models/reparm_unet.py:55-61,139); fp32: conv_igemm.
+    Forward with statistics, forward with the deployed path's bias + ReLU epilogue, dgrad; against F.conv2d on the CPU."""
     from unet_amd import ops
     N, H, W, Cin, Cout = shape
+    kh, kw = k
     x = q(rnd((N, Cin, H, W), 111), dt)
-    w = q(rnd((Cout, Cin, 5, 5), 112, (Cin * 25) ** -0.5), dt)
+    w = q(rnd((Cout, Cin, kh, kw), 112, (Cin * kh * kw) ** -0.5), dt)
     b = rnd((Cout,), 113)
     x.requires_grad_(True); w.requires_grad_(True)
-    ref = F.conv2d(x, w, b, padding=2)
+    ref = F.conv2d(x, w, b, padding=(kh // 2, kw // 2))
     dyv = q(rnd(tuple(ref.shape), 114), dt)
     ref.backward(dyv)
 
     xa = to_act(x.detach(), dt, dev)
     ya = ops.dense(N, H, W, Cout, dt, dev)
     wp = ops.pack_weights(w.detach().to(dev), 0, dt)
-    rows = ops.conv_fwd(xa, wp, b.to(dev), ya, 5, 5, Cin, Cout, stats=True)
-    close(from_act(ya), ref.detach(), dt, "conv5 fwd")
+    rows = ops.conv_fwd(xa, wp, b.to(dev), ya, kh, kw, Cin, Cout, stats=True)
+    close(from_act(ya), ref.detach(), dt, "conv fwd")
     s = rows.double().sum(0).cpu()
     r = ref.detach().double()
     close(s[:, 0].float(), r.sum((0, 2, 3)).float(), dt, "stats sum", f32_out=True)
     close(s[:, 1].float(), (r * r).sum((0, 2, 3)).float(), dt, "stats sumsq", f32_out=True)
 
-    ops.conv_fwd(xa, wp, b.to(dev), ya, 5, 5, Cin, Cout, relu=True)
-    close(from_act(ya), torch.relu(ref.detach()), dt, "conv5 + ReLU")
+    ops.conv_fwd(xa, wp, b.to(dev), ya, kh, kw, Cin, Cout, relu=True)
+    close(from_act(ya), torch.relu(ref.detach()), dt, "conv + ReLU")
 
     dza = to_act(dyv, dt, dev)
     dxa = ops.dense(N, H, W, Cin, dt, dev)
-    ops.conv_fwd(dza, ops.pack_weights(w.detach().to(dev), 1, dt), None, dxa, 5, 5, Cout, Cin)
-    close(from_act(dxa), x.grad, dt, "conv5 dgrad")
+    ops.conv_fwd(dza, ops.pack_weights(w.detach().to(dev), 1, dt), None, dxa, kh, kw, Cout, Cin)
+    close(from_act(dxa), x.grad, dt, "conv dgrad")
 
 
 @pytest.mark.parametrize("dt", [0, 1])

@@ -22,21 +22,22 @@
 #include <cstdlib>
 
 
-template <int WC, int KS = 3>
+template <int WC, int KH = 3, int KW = 3>
 struct Cv2Cfg {
-    static_assert(KS == 3 || (KS == 5 && WC == 1), "3x3, or 5x5 on 64-channel tiles");
+    static_assert((KH == 3 && KW == 3) || WC == 1, "kernels other than 3x3 run on 64-channel tiles");
     static constexpr int BCO = 64 * WC;            // output channels per workgroup
     static constexpr int NWR = 8 / WC;             // wave row groups
     static constexpr int TH = 16, TW = 32;
     static constexpr int RW = TH / NWR;            // tile rows per wave (4 or 2)
     static constexpr int NPG = RW * 2;             // 16-pixel groups per wave
-    static constexpr int HP = TW + KS - 1;         // halo row pitch (records): 34 / 36
-    static constexpr int HREC = (TH + KS - 1) * HP;   // 612 / 720 records
+    static constexpr int HP = TW + KW - 1;         // halo row pitch (records): 32 / 34 / 36
+    static constexpr int HREC = (TH + KH - 1) * HP;   // 612 records for 3x3, 720 for 5x5
     static constexpr int H_PIECES = (HREC + 127) / 128 * 8;      // 16 records per 1-KiB piece, padded to a multiple of 8: 40 / 48
     static constexpr int H_BYTES = H_PIECES * 1024;
     // taps per phase: one kernel column (kw) for 128-channel tiles and for 5x5; the whole 3x3 kernel for 64-channel tiles
-    static constexpr int TPP = (WC == 2 || KS == 5) ? KS : 9;
-    static constexpr int NPH = KS * KS / TPP;      // phases per 32-channel chunk
+    // (k x 1 and 1 x k, the RepUNet training branches of models/reparm_unet.py:55-61: the whole kernel, one phase)
+    static constexpr int TPP = (WC == 2 || (KH == 5 && KW == 5)) ? KH : KH * KW;
+    static constexpr int NPH = KH * KW / TPP;      // phases per 32-channel chunk
     static constexpr int W_PIECES = TPP * BCO / 16;
     static constexpr int W_BYTES = W_PIECES * 1024;
     static constexpr int OFF_H = 0, OFF_W = 2 * H_BYTES, OFF_RED = OFF_W + 2 * W_BYTES;
@@ -44,7 +45,9 @@ struct Cv2Cfg {
     static constexpr int OFF_BIAS = OFF_RED + RED_BYTES;        // two 1-KiB slots: the tile's BCO fp32 biases
     // producer scheme (WC == 2): the per-lane source offsets of each producer wave's 10 halo pieces, [wave][piece][lane]
     static constexpr int OFF_HOFF = OFF_BIAS + 2 * 1024;
-    static constexpr bool ASYM = WC == 2 || KS == 5;            // producer scheme: waves 0-3 issue every request
+    // producer scheme: waves 0-3 issue every request.  Not for one-phase chunks: there a wave refills, after its own
+    // epilogue, exactly the halo pieces it borrowed as its transposition tile, which only the symmetric split guarantees.
+    static constexpr bool ASYM = WC == 2 || (KH == 5 && KW == 5);
     static constexpr int HOFF_BYTES = ASYM ? 4 * (H_PIECES / 4) * 256 : 0;
     static constexpr int SMEM = OFF_HOFF + HOFF_BYTES;
     static_assert(SMEM <= 160 * 1024, "LDS budget");
@@ -67,12 +70,14 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // SPEC = true (64-channel tiles of the specialised kernel, no deferred statistics): SPECIALISED REQUEST WAVES, as in
 // conv_wgrad2.hip.  The workgroup has 12 waves, three per SIMD: waves 0-7 are the matrix waves, waves 8-11 issue every
 // LDS-DMA request (19-20 pieces per chunk each), wait for them and meet the others at the barriers.
-// KS = 5: the 5x5 convolutions of a deployed RepUNet (models/reparm_unet.py:139, kernel_sizes [3,5] folded) and of its
+// KH x KW = 5x5: the 5x5 convolutions of a deployed RepUNet (models/reparm_unet.py:139, kernel_sizes [3,5] folded) and of its
 // training branches, on 64-channel tiles with one kernel column (5 taps) per phase.
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KS = 3>
+// 3x1 / 5x1 / 1x3 / 1x5: the vertical and horizontal branches of the AsymmConvBlock (models/reparm_unet.py:55-61), whole
+// kernel per phase; a 1 x k kernel is k columns of one row each, its A fragments double-buffered per column.
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
-    using C = Cv2Cfg<WC, KS>;
-    static_assert(KS == 3 || (!GEN && !DST && !SPEC), "5x5: the specialised kernel only");
+    using C = Cv2Cfg<WC, KH, KW>;
+    static_assert((KH == 3 && KW == 3) || (!GEN && !DST && !SPEC), "other than 3x3: the specialised kernel only");
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -95,9 +100,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // A (weights): record = tapslot*BCO + wc*64 + ct*16 + l15, k-slot g
     const int a_base = C::OFF_W + (wc * 64 + l15) * 64 + ((g ^ swz64(l15)) << 4);
     // B (halo): record = (wr*RW + rr + kh)*HP + cc*16 + l15 + kw, k-slot g
-    int b_base[KS][2];
+    int b_base[KW][2];
 #pragma unroll
-    for (int kw = 0; kw < KS; ++kw)
+    for (int kw = 0; kw < KW; ++kw)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int col = cc * 16 + l15 + kw;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     auto halo_mask = [&](const Tile& t) {
         const int r0 = t.h0 - a.pad_h, c0 = t.w0 - a.pad_w;
         unsigned m = 0;
-        if (r0 >= 0 && r0 + C::TH + KS - 1 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return (1u << HPW) - 1u;     // interior tile (wave-uniform)
+        if (r0 >= 0 && r0 + C::TH + KH - 1 <= a.Hin && c0 >= 0 && c0 + HP <= a.Win) return (1u << HPW) - 1u;     // interior tile (wave-uniform)
         int lane_ = lane;
         asm volatile("" : "+v"(lane_));
 #pragma unroll
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
         if (p >= C::W_PIECES) return 0;
         const int r0 = p * 16;
         const int j = r0 / BCO, cou = t.cb * BCO + (r0 % BCO);
-        const int tap = (NPH == 1) ? j : j * KS + ph;                 // a one-column phase holds taps (kh = j, kw = ph)
+        const int tap = (NPH == 1) ? j : j * KW + ph;                 // a one-column phase holds taps (kh = j, kw = ph)
         const long long offu = ((long long)(tap * a.Cout + cou) * a.Cin + c * 32) * 2;   // wave-uniform
         unsigned v = woff;
         if (generic) {
@@ -391,13 +396,15 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                 // often than tap by tap.  (Tap by tap the LDS reads of a 128-channel tile were 2,300 of the 3,072 cycles a
                 // phase's MFMAs take: the kernel was as much LDS-bound as MFMA-bound.)  The A fragments of the column's
                 // three taps stay in registers (12 x 4 VGPRs); B fragments run DEPTH steps ahead in a small ring.
-                constexpr int HR = RW + KS - 1, KWP = TPP / KS, DEPTH = 2, RING = 3, NSTEP = KWP * HR * 2;
-                static_assert(KS == 3 || KWP == 1, "the cross-column A prefetch below is written for three kernel rows");
-                uint4 fa[KS][4], fb[RING];
+                constexpr int HR = RW + KH - 1, KWP = TPP / KH, DEPTH = 2, RING = 3, NSTEP = KWP * HR * 2;
+                static_assert(KH == 3 || KH == 1 || KWP == 1, "cross-column A prefetch: three kernel rows, or one (double-buffered)");
+                constexpr int NA = KH == 1 ? 2 : KH;           // A register sets: one per kernel row; 1 x k: two, alternating per column
+                uint4 fa[NA][4], fb[RING];
                 auto load_a = [&](int kwi, int kh) {
-                    const int j = (KWP == 1) ? kh : kh * KS + kwi;         // tap slot inside the phase's weight image
+                    const int j = (KWP == 1) ? kh : kh * KW + kwi;         // tap slot inside the phase's weight image
+                    const int set = KH == 1 ? (kwi & 1) : kh;
 #pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) fa[kh][ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
+                    for (int ct = 0; ct < 4; ++ct) fa[set][ct] = *(const uint4*)(wb + a_base + j * (BCO * 64) + ct * 1024);
                 };
                 auto load_b = [&](int step) {
                     const int kw = ph * KWP + step / (HR * 2), hr = (step >> 1) % HR, cc = step & 1;
@@ -415,22 +422,26 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                         if (st + DEPTH < NSTEP) fb[(st + DEPTH) % RING] = load_b(st + DEPTH);
                         // A fragments: a column's kh = 1, 2 taps follow its first steps; the next column's taps are
                         // requested as soon as the registers they replace have seen their last MFMA
-                        if (kwi == 0 && 1 + 2 * hr + cc < KS) load_a(0, 1 + 2 * hr + cc);      // kh = 1.. follow the first steps
-                        if (cc == 0 && kwi + 1 < KWP && hr == RW) load_a(kwi + 1, 0);
-                        if (cc == 0 && kwi + 1 < KWP && hr == RW + 1) load_a(kwi + 1, 1);
-                        if (cc == 0 && kwi > 0 && hr == 0) load_a(kwi, 2);
+                        if (kwi == 0 && 1 + 2 * hr + cc < KH) load_a(0, 1 + 2 * hr + cc);      // kh = 1.. follow the first steps
+                        if constexpr (KH == 3) {
+                            if (cc == 0 && kwi + 1 < KWP && hr == RW) load_a(kwi + 1, 0);
+                            if (cc == 0 && kwi + 1 < KWP && hr == RW + 1) load_a(kwi + 1, 1);
+                            if (cc == 0 && kwi > 0 && hr == 0) load_a(kwi, 2);
+                        } else if constexpr (KH == 1) {
+                            if (cc == 0 && hr == 0 && kwi + 1 < KWP) load_a(kwi + 1, 0);       // the other register set
+                        }
 #pragma unroll
-                        for (int kh = 0; kh < KS; ++kh) {
+                        for (int kh = 0; kh < KH; ++kh) {
                             const int rr = hr - kh;
                             if (rr < 0 || rr >= RW) continue;
                             const int pg = rr * 2 + cc;
 #pragma unroll
                             for (int ct = 0; ct < 4; ++ct) {
 #ifdef CV2_X_NOMFMA
-                                asm volatile("" :: "v"(__builtin_bit_cast(bf16x8, fa[kh][ct])), "v"(__builtin_bit_cast(bf16x8, fb[st % RING])));
+                                asm volatile("" :: "v"(__builtin_bit_cast(bf16x8, fa[KH == 1 ? (kwi & 1) : kh][ct])), "v"(__builtin_bit_cast(bf16x8, fb[st % RING])));
 #else
                                 acc[ct][pg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(bf16x8, fa[kh][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
+                                    __builtin_bit_cast(bf16x8, fa[KH == 1 ? (kwi & 1) : kh][ct]), __builtin_bit_cast(bf16x8, fb[st % RING]), acc[ct][pg], 0, 0, 0);
 #endif
                             }
                         }
@@ -670,11 +681,11 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KS = 3>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
-    using C = Cv2Cfg<WC, KS>;
+    using C = Cv2Cfg<WC, KH, KW>;
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KS>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     // STREAMING STORES for outputs far larger than the L2s (8 x 4 MiB): the store burst of one round of tiles (32 workgroups
     // x 128 KiB per XCD) otherwise evicts the weights and halos the next round wants.  Same box: 256->256 @128^2 (268 MB
@@ -685,7 +696,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KS>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -738,4 +749,13 @@ bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
     return (Cin & 31) == 0 && (Cout & 63) == 0 && (Hout & 15) == 0 && (Wout & 31) == 0 && (flags & 1) == 0 && (csplit & 63) == 0;
 }
 int conv5_rows(int N, int Hout, int Wout) { return N * (Hout / 16) * (Wout / 32); }
-int dispatch_conv5(const ConvArgs& a, hipStream_t s) { return launch_conv2<1, false, false, false, 5>(a, s); }
+int dispatch_conv5(const ConvArgs& a, hipStream_t s) { return launch_conv2<1, false, false, false, 5, 5>(a, s); }
+// k x 1 / 1 x k, same eligibility and row count
+int dispatch_convk(int kh, int kw, const ConvArgs& a, hipStream_t s) {
+    if (kh == 3 && kw == 1) return launch_conv2<1, false, false, false, 3, 1>(a, s);
+    if (kh == 5 && kw == 1) return launch_conv2<1, false, false, false, 5, 1>(a, s);
+    if (kh == 1 && kw == 3) return launch_conv2<1, false, false, false, 1, 3>(a, s);
+    if (kh == 1 && kw == 5) return launch_conv2<1, false, false, false, 1, 5>(a, s);
+    unet_set_error("no LDS-DMA instantiation for a %dx%d kernel", kh, kw);
+    return -1;
+}

@@ -257,8 +257,10 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s);
 bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit);
 int conv5_rows(int N, int Hout, int Wout);
 int dispatch_conv5(const ConvArgs& a, hipStream_t s);
+int dispatch_convk(int kh, int kw, const ConvArgs& a, hipStream_t s);
 static bool use_conv5(int dtype, int kh, int kw, int sh, int epi, int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
-    return dtype == UNET_BF16 && kh == 5 && kw == 5 && sh == 1 && epi == 0 && conv5_v2_ok(Cin, Cout, Hout, Wout, flags, csplit);
+    const bool shape = (kh == 5 && kw == 5) || ((kh == 3 || kh == 5) && kw == 1) || (kh == 1 && (kw == 3 || kw == 5));
+    return dtype == UNET_BF16 && shape && sh == 1 && epi == 0 && conv5_v2_ok(Cin, Cout, Hout, Wout, flags, csplit);
 }
 // bf16 ConvTranspose2d forward / dgrad on whole tiles (conv_t2.hip)
 bool convT2_fwd_ok(const ConvArgs& a);
@@ -332,7 +334,7 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     }
     if (use_conv5(dtype, kh, kw, stride_h, epi, Cin, Cout, Hout, Wout, flags, csplit)) {
         UNET_CHECK((size_t)25 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");
-        return dispatch_conv5(a, s);
+        return (kh == 5 && kw == 5) ? dispatch_conv5(a, s) : dispatch_convk(kh, kw, a, s);
     }
     if (dtype == UNET_BF16 && epi == 1 && kh == 1 && kw == 1 && stride_h == 1 && convT2_fwd_ok(a)) return convT2_fwd(a, s);
     if (dtype == UNET_BF16 && epi == 0 && kh == 2 && kw == 1 && stride_h == 2 && convT2_dgrad_ok(a)) return convT2_dgrad(a, s);
