@@ -53,6 +53,13 @@ struct Cv2Cfg {
     static_assert(SMEM <= 160 * 1024, "LDS budget");
 };
 
+// TIMING-ONLY VARIANTS (never in the shipped library; results are wrong by construction): make EXTRA=-DCV2_X_<NAME>
+// LIB=../libunet_hip_x_<name>.so BUILD=build_x_<name>, compared on one box with tools/ab_variants.sh.
+//   CV2_X_NODMA   no LDS-DMA request is issued (the loop multiplies whatever the LDS holds)
+//   CV2_X_NOMFMA  fragments are read, no MFMA is issued
+//   CV2_X_NOEPI   accumulators stay live, nothing is stored
+//   CV2_X_NOBAR   the per-phase barrier is dropped
+// (conv_wgrad2.hip: CV2_X_NODMA, CV2_X_NOWAIT = request waves do not wait for their requests.)  DESIGN 4.1 has the numbers.
 #ifdef CV2_TRACE
 // diagnostic build only (make TRACE=1): s_memtime stamps of block 0, waves 0 and 4
 __device__ unsigned long long* g_cv2_trace = nullptr;
