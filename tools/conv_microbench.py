@@ -20,7 +20,8 @@ LAYERS = [  # name, Cin, Cout, H (square), from SURVEY 8d
 
 
 def timeit(fn, iters):
-    fn()
+    for _ in range(4):          # the first launches of a process run at a lower clock: warm up before timing
+        fn()
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
