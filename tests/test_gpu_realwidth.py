@@ -96,8 +96,14 @@ def test_conv5x5_and_asymmetric_real_widths(dev, dt, k, shape):
 
     dza = to_act(dyv, dt, dev)
     dxa = ops.dense(N, H, W, Cin, dt, dev)
-    ops.conv_fwd(dza, ops.pack_weights(w.detach().to(dev), 1, dt), None, dxa, kh, kw, Cout, Cin)
+    wd = ops.pack_weights(w.detach().to(dev), 1, dt)
+    ops.conv_fwd(dza, wd, None, dxa, kh, kw, Cout, Cin)
     close(from_act(dxa), x.grad, dt, "conv dgrad")
+    # the branch dgrads of a block are summed into one dx (rep_engine: accumulate=True on all but the first)
+    base = q(rnd((N, Cin, H, W), 115), dt)
+    dxb = to_act(base, dt, dev)
+    ops.conv_fwd(dza, wd, None, dxb, kh, kw, Cout, Cin, accumulate=True)
+    close(from_act(dxb), base + x.grad, dt, "conv dgrad, accumulated")
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -127,6 +133,10 @@ def test_conv3x3_real_widths(dev, dt, shape):
     wd = ops.pack_weights(w.detach().to(dev), 1, dt)
     ops.conv_fwd(dza, wd, None, dxa, 3, 3, Cout, Cin)
     close(from_act(dxa), x.grad, dt, "conv dgrad")
+    base = q(rnd((N, Cin, H, W), 105), dt)
+    dxb = to_act(base, dt, dev)
+    ops.conv_fwd(dza, wd, None, dxb, 3, 3, Cout, Cin, accumulate=True)
+    close(from_act(dxb), base + x.grad, dt, "conv dgrad, accumulated")
 
     # the decoder's first conv hands the two halves of the concat gradient to two buffers and takes the ConvTranspose2d
     # bias gradient from the epilogue's statistics rows (engine.block_bwd, split_f)

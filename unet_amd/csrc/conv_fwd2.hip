@@ -81,10 +81,13 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // training branches, on 64-channel tiles with one kernel column (5 taps) per phase.
 // 3x1 / 5x1 / 1x3 / 1x5: the vertical and horizontal branches of the AsymmConvBlock (models/reparm_unet.py:55-61), whole
 // kernel per phase; a 1 x k kernel is k columns of one row each, its A fragments double-buffered per column.
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3>
+// ACC = true (specialised kernel, no request waves): flags bit 0 ADDS the result to what the destination holds -- the branch
+// dgrads of a RepUNet block (models/reparm_unet.py:62-72,110-122: six convolutions of one input) summed into one dx.
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC, KH, KW>;
     static_assert((KH == 3 && KW == 3) || (!GEN && !DST && !SPEC), "other than 3x3: the specialised kernel only");
+    static_assert(!ACC || (!GEN && !DST && !SPEC), "accumulating epilogue: the specialised kernel without request waves");
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -516,6 +519,27 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                         }
                     }
                 }
+                if constexpr (ACC) {
+                    if (a.flags & 1) {
+                        // the destination's values join the fp32 accumulators in the accumulator layout (lane = pixel l15,
+                        // four channels 4*ge..+3 of each 16-channel tile: 8 bytes per load, a pixel's four ge-lanes cover 32
+                        // contiguous bytes), so the sum is rounded once, as in the generic kernel
+                        const char* obase = ybase + ((size_t)l15e * ld + 4 * ge) * 2;
+                        const size_t orow = (size_t)a.Wout * ld * 2, ohalf = (size_t)16 * ld * 2;
+#pragma unroll
+                        for (int pg = 0; pg < NPG; ++pg) {
+                            const char* op = obase + (pg >> 1) * orow + (pg & 1) * ohalf;
+                            uint2 old[4];
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) old[ct] = *(const uint2*)(op + ct * 32);
+#pragma unroll
+                            for (int ct = 0; ct < 4; ++ct) {
+                                acc[ct][pg][0] += __uint_as_float(old[ct].x << 16); acc[ct][pg][1] += __uint_as_float(old[ct].x & 0xffff0000u);
+                                acc[ct][pg][2] += __uint_as_float(old[ct].y << 16); acc[ct][pg][3] += __uint_as_float(old[ct].y & 0xffff0000u);
+                            }
+                        }
+                    }
+                }
                 // pass 1 (forward only): BN partial statistics.  Every lane stores its (sum, sum of squares) pair:
                 // lanes other than the group's first aim at a scratch slot, which is cheaper than sixteen exec-mask
                 // round trips.
@@ -688,11 +712,11 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC, KH, KW>;
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC>, C::SMEM)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     // STREAMING STORES for outputs far larger than the L2s (8 x 4 MiB): the store burst of one round of tiles (32 workgroups
     // x 128 KiB per XCD) otherwise evicts the weights and halos the next round wants.  Same box: 256->256 @128^2 (268 MB
@@ -703,7 +727,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -711,11 +735,11 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
 
 static bool conv2_gen(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
     const int bco = Cout > 64 ? 128 : 64;
-    return (Cin & 31) != 0 || (Cout % bco) != 0 || (Hout & 15) != 0 || (Wout & 31) != 0 || (flags & 1) != 0 || (csplit & 63) != 0;
+    return (Cin & 31) != 0 || (Cout % bco) != 0 || (Hout & 15) != 0 || (Wout & 31) != 0 || (csplit & 63) != 0;
 }
 // deferred statistics (specialised 64-channel kernel, statistics wanted, not per-image rows): ONE row per workgroup
 static bool conv2_defer(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
-    return Cout <= 64 && !conv2_gen(Cin, Cout, Hout, Wout, flags, csplit) && (flags & 4) == 0;
+    return Cout <= 64 && !conv2_gen(Cin, Cout, Hout, Wout, flags, csplit) && (flags & 5) == 0;
 }
 // stat rows the bf16 3x3 path writes: one per 16x32 pixel tile, or one per persistent workgroup (deferred statistics)
 int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int csplit) {
@@ -738,6 +762,7 @@ int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int cspl
 //    form (128-channel dgrad into a 2.1 GB tensor: 1.106 -> 1.147 ms).
 int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     const bool gen = conv2_gen(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit);
+    if (!gen && (a.flags & 1)) return a.Cout > 64 ? launch_conv2<2, false, false, false, 3, 3, true>(a, s) : launch_conv2<1, false, false, false, 3, 3, true>(a, s);
     if (a.Cout > 64) return gen ? launch_conv2<2, true>(a, s) : launch_conv2<2, false>(a, s);
     if (gen) return launch_conv2<1, true>(a, s);
     // deferred statistics put a workgroup's sums (over tiles of several images) into one row: not for flags bit 2
@@ -753,16 +778,19 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
 // 5x5 stride 1 on whole 16x32 tiles and whole 64-channel blocks: the LDS-DMA kernel (one stats row per pixel tile); everything
 // else stays on conv_igemm.hip (8x32 tiles).  unet_conv_tiles() asks the same question to size the statistics rows.
 bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit) {
-    return (Cin & 31) == 0 && (Cout & 63) == 0 && (Hout & 15) == 0 && (Wout & 31) == 0 && (flags & 1) == 0 && (csplit & 63) == 0;
+    return (Cin & 31) == 0 && (Cout & 63) == 0 && (Hout & 15) == 0 && (Wout & 31) == 0 && (csplit & 63) == 0;
 }
 int conv5_rows(int N, int Hout, int Wout) { return N * (Hout / 16) * (Wout / 32); }
-int dispatch_conv5(const ConvArgs& a, hipStream_t s) { return launch_conv2<1, false, false, false, 5, 5>(a, s); }
+int dispatch_conv5(const ConvArgs& a, hipStream_t s) {
+    return (a.flags & 1) ? launch_conv2<1, false, false, false, 5, 5, true>(a, s) : launch_conv2<1, false, false, false, 5, 5>(a, s);
+}
 // k x 1 / 1 x k, same eligibility and row count
 int dispatch_convk(int kh, int kw, const ConvArgs& a, hipStream_t s) {
-    if (kh == 3 && kw == 1) return launch_conv2<1, false, false, false, 3, 1>(a, s);
-    if (kh == 5 && kw == 1) return launch_conv2<1, false, false, false, 5, 1>(a, s);
-    if (kh == 1 && kw == 3) return launch_conv2<1, false, false, false, 1, 3>(a, s);
-    if (kh == 1 && kw == 5) return launch_conv2<1, false, false, false, 1, 5>(a, s);
+    const bool acc = (a.flags & 1) != 0;
+    if (kh == 3 && kw == 1) return acc ? launch_conv2<1, false, false, false, 3, 1, true>(a, s) : launch_conv2<1, false, false, false, 3, 1>(a, s);
+    if (kh == 5 && kw == 1) return acc ? launch_conv2<1, false, false, false, 5, 1, true>(a, s) : launch_conv2<1, false, false, false, 5, 1>(a, s);
+    if (kh == 1 && kw == 3) return acc ? launch_conv2<1, false, false, false, 1, 3, true>(a, s) : launch_conv2<1, false, false, false, 1, 3>(a, s);
+    if (kh == 1 && kw == 5) return acc ? launch_conv2<1, false, false, false, 1, 5, true>(a, s) : launch_conv2<1, false, false, false, 1, 5>(a, s);
     unet_set_error("no LDS-DMA instantiation for a %dx%d kernel", kh, kw);
     return -1;
 }
