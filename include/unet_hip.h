@@ -256,6 +256,12 @@ int unet_branch_sum_act(int dtype, int relu, int nb, const void* const* z, const
 int unet_gn_bwd(int dtype, const void* u, const void* z, void* dz, int N, long long HW, int C, int groups,
                 const float* gamma, const float* mean, const float* invstd,
                 float* dgamma, float* dbeta, double* acc_ws, float* coef_ws, void* stream);
+/* GroupNorm backward of the nb <= 8 branches of one MultiConvBlock (models/reparm_unet.py:114-122), which share u: u is
+ * read once per pass instead of once per branch.  z/dz/gamma/mean/invstd/dgamma/dbeta are HOST arrays of nb device
+ * pointers; acc_ws: nb*(N*C*2+C*2) doubles, coef_ws: nb*3*N*C floats.  Same arithmetic per branch as unet_gn_bwd. */
+int unet_gn_bwd_multi(int dtype, int nb, const void* u, const void* const* z, void* const* dz, int N, long long HW, int C, int groups,
+                      const float* const* gamma, const float* const* mean, const float* const* invstd,
+                      float* const* dgamma, float* const* dbeta, double* acc_ws, float* coef_ws, void* stream);
 
 /* ---- RepUNet fold (switch_to_deploy) -- models/reparm_unet.py:28-37,74-82,124-135; bit-exact fp32 */
 int unet_fold_asymm(int k, int O, int I, const float* w_sq, const float* w_ve, const float* w_ho,

@@ -225,3 +225,38 @@ def test_repunet_groupnorm_64_channels_bf16_stats_stay_per_image(dev):
     for n in range(3):              # per image: a wrong statistic of one image must not hide behind the others
         e = float((out16[n].float().cpu() - ref[n]).norm() / ref[n].norm())
         assert e < 3e-2, (n, e)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 6), (3, 8, 8, 128, 3), (1, 12, 20, 24, 8), (2, 4, 8, 1024, 6)])
+def test_gn_bwd_multi_matches_per_branch_and_torch(dev, dt, shape):
+    """GroupNorm backward of all branches of a block in one pass (they share the upstream gradient,
+    /root/reference/models/reparm_unet.py:114-122) against the per-branch entry point and torch autograd."""
+    import torch.nn.functional as F
+    from unet_amd import ops
+    from test_gpu_kernels import q, rnd, to_act, from_act
+    N, H, W, C, nb = shape
+    groups = min(8, C)
+    u = q(rnd((N, C, H, W), 301), dt)
+    zs = [q(rnd((N, C, H, W), 310 + b) * (1.0 + 0.3 * b) + 0.1 * b, dt) for b in range(nb)]
+    gammas = [rnd((C,), 330 + b).abs() + 0.5 for b in range(nb)]
+    betas = [rnd((C,), 350 + b) * 0.2 for b in range(nb)]
+    ua = to_act(u, dt, dev)
+    zas, sts = [], []
+    for b in range(nb):
+        za = to_act(zs[b], dt, dev)
+        zz = zs[b].double()
+        rows = torch.stack([zz.sum((2, 3)), (zz * zz).sum((2, 3))], -1).float().reshape(N, C, 2).to(dev).contiguous()
+        sts.append(ops.gn_finalize(rows, N, H * W, gammas[b].to(dev), betas[b].to(dev), groups))
+        zas.append(za)
+    multi = ops.gn_bwd_multi(ua, zas, sts, [g.to(dev) for g in gammas])
+    for b in range(nb):
+        dz1, dg1, db1 = ops.gn_bwd(ua, zas[b], sts[b], gammas[b].to(dev))
+        dzm, dgm, dbm = multi[b]
+        assert torch.equal(dzm.buf, dz1.buf), f"branch {b} dz"
+        assert float((dgm - dg1).abs().max()) <= 1e-6 * float(dg1.abs().max()) and float((dbm - db1).abs().max()) <= 1e-6 * float(db1.abs().max())
+        if dt == 0:
+            zt = zs[b].clone().requires_grad_(True)
+            gt, bt = gammas[b].clone().requires_grad_(True), betas[b].clone().requires_grad_(True)
+            F.group_norm(zt, groups, gt, bt, 1e-5).backward(u)
+            assert relmax(from_act(dzm), zt.grad) < 2e-5 and relmax(dgm.cpu(), gt.grad) < 2e-5 and relmax(dbm.cpu(), bt.grad) < 2e-5

@@ -222,6 +222,167 @@ __global__ void dgb_store_kernel(const double* __restrict__ dgb, float* __restri
     if (c < C) { dgamma[c] = (float)dgb[c * 2]; dbeta[c] = (float)dgb[c * 2 + 1]; }
 }
 
+// ---- GroupNorm backward of ALL branches of a block in one pass each ---------------------------------------------
+// The branches of a MultiConvBlock (models/reparm_unet.py:114-122) share their upstream gradient u (the block's ReLU-masked
+// dy): per-branch launches read u six times in the reduction and six times in the apply pass.  Here u is read once per
+// pass: reduce 12 -> 7 tensor reads, apply 18 -> 13 accesses for kernel_sizes [3,5].
+struct GnMultiArgs {
+    const void* z[MAX_BRANCH];
+    void* dz[MAX_BRANCH];
+    const float* gamma[MAX_BRANCH];
+    const float* mean[MAX_BRANCH];
+    const float* invstd[MAX_BRANCH];
+    float* dgamma[MAX_BRANCH];
+    float* dbeta[MAX_BRANCH];
+    int nb;
+};
+
+// acc + b*acc_stride: [N][C][2] = (sum_p u, sum_p u*z_b)
+template <typename T>
+__global__ __launch_bounds__(256) void multi_pair_reduce_kernel(GnMultiArgs a, const T* __restrict__ u, long long HW, int C,
+                                                                double* __restrict__ acc, size_t acc_stride) {
+    constexpr int EPV = TT<T>::EPV;
+    extern __shared__ float sm_f[];                 // [pl][cg][EPV], reused per reduced quantity
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    const bool active = pl < PL;
+    const int n = blockIdx.y;
+    float p1[EPV], p2[MAX_BRANCH][EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) p1[e] = 0.f;
+#pragma unroll
+    for (int b = 0; b < MAX_BRANCH; ++b)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) p2[b][e] = 0.f;
+    if (active) {
+        for (long long p = (long long)blockIdx.x * PL + pl; p < HW; p += (long long)gridDim.x * PL) {
+            const long long off = ((long long)n * HW + p) * C + cg * EPV;
+            uint4 rz[MAX_BRANCH];
+            const uint4 ru = *(const uint4*)(u + off);
+#pragma unroll
+            for (int b = 0; b < MAX_BRANCH; ++b)
+                if (b < a.nb) rz[b] = *(const uint4*)((const T*)a.z[b] + off);
+            float fu[EPV];
+            Vec16<T>::unpack(ru, fu);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) p1[e] += fu[e];
+#pragma unroll
+            for (int b = 0; b < MAX_BRANCH; ++b) {
+                if (b < a.nb) {
+                    float fv[EPV];
+                    Vec16<T>::unpack(rz[b], fv);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) p2[b][e] = fmaf(fu[e], fv[e], p2[b][e]);
+                }
+            }
+        }
+    }
+    const int per = G * EPV;
+    // quantity q = 0: sum u (written to every branch's slot 0); q = 1 + b: sum u*z_b
+#pragma unroll
+    for (int q = 0; q <= MAX_BRANCH; ++q) {
+        if (q > a.nb) break;
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) sm_f[(pl * G + cg) * EPV + e] = q == 0 ? p1[e] : p2[q > 0 ? q - 1 : 0][e];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += 256) {
+            float s = 0.f;
+            for (int pp = 0; pp < PL; ++pp) s += sm_f[pp * per + i];
+            if (q == 0) {
+                for (int b = 0; b < a.nb; ++b) atomicAdd(&acc[b * acc_stride + ((size_t)n * C + i) * 2], (double)s);
+            } else {
+                atomicAdd(&acc[(q - 1) * acc_stride + ((size_t)n * C + i) * 2 + 1], (double)s);
+            }
+        }
+    }
+}
+
+// blockIdx.y = branch: the per-branch finalize of gn_bwd_finalize_kernel
+__global__ __launch_bounds__(256) void gn_bwd_finalize_multi_kernel(GnMultiArgs a, const double* __restrict__ acc0, size_t acc_stride,
+                                                                    int N, int C, int groups, double m,
+                                                                    float* __restrict__ coef0, size_t coef_stride) {
+    extern __shared__ double sm_d[];          // [groups][2]
+    const int n = blockIdx.x, b = blockIdx.y;
+    const double* acc = acc0 + b * acc_stride;
+    double* dgb = (double*)acc + (size_t)N * C * 2;
+    float* cA = coef0 + b * coef_stride; float* cB = cA + (size_t)N * C; float* cD = cB + (size_t)N * C;
+    const float* gamma = a.gamma[b]; const float* mean = a.mean[b]; const float* invstd = a.invstd[b];
+    const int cg = C / groups;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        const double mu = mean[n * groups + g], is = invstd[n * groups + g];
+        double t1 = 0.0, t2 = 0.0;
+        for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            const double s1 = acc[((size_t)n * C + c) * 2], s2 = acc[((size_t)n * C + c) * 2 + 1];
+            t1 += (double)gamma[c] * s1;
+            t2 += (double)gamma[c] * is * (s2 - mu * s1);
+        }
+        sm_d[g * 2] = t1 / m;
+        sm_d[g * 2 + 1] = t2 / m;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int g = c / cg;
+        const double mu = mean[n * groups + g], is = invstd[n * groups + g];
+        const double c1 = sm_d[g * 2], c2 = sm_d[g * 2 + 1];
+        cA[(size_t)n * C + c] = (float)(is * (double)gamma[c]);
+        cB[(size_t)n * C + c] = (float)(-is * is * c2);
+        cD[(size_t)n * C + c] = (float)(-is * c1 + is * is * mu * c2);
+        const double s1 = acc[((size_t)n * C + c) * 2], s2 = acc[((size_t)n * C + c) * 2 + 1];
+        atomicAdd(&dgb[c * 2], is * (s2 - mu * s1));
+        atomicAdd(&dgb[c * 2 + 1], s1);
+    }
+}
+
+// dz_b = A_b[n][c]*u + B_b[n][c]*z_b + D_b[n][c] for every branch; a thread keeps MU pixels of u in registers across the branches
+template <typename T>
+__global__ __launch_bounds__(256) void multi_affine2_kernel(GnMultiArgs a, const T* __restrict__ u, const float* __restrict__ coef0,
+                                                            size_t coef_stride, int N, long long HW, int C) {
+    constexpr int EPV = TT<T>::EPV, MU = 4;
+    const int G = C / EPV, PL = 256 / G;
+    const int pl = threadIdx.x / G, cg = threadIdx.x - pl * G;
+    if (pl >= PL) return;
+    const int n = blockIdx.y;
+    const long long stride = (long long)gridDim.x * PL;
+    const size_t NC = (size_t)N * C, co = (size_t)n * C + cg * EPV;
+    for (long long p0 = (long long)blockIdx.x * PL + pl; p0 < HW; p0 += stride * MU) {
+        uint4 ru[MU];
+#pragma unroll
+        for (int i = 0; i < MU; ++i)
+            if (p0 + i * stride < HW) ru[i] = *(const uint4*)(u + ((long long)n * HW + p0 + i * stride) * C + cg * EPV);
+#pragma unroll
+        for (int b = 0; b < MAX_BRANCH; ++b) {
+            if (b >= a.nb) break;
+            const float* cf = coef0 + b * coef_stride + co;
+            float A[EPV], B[EPV], D[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { A[e] = cf[e]; B[e] = cf[NC + e]; D[e] = cf[2 * NC + e]; }
+            uint4 rz[MU];
+#pragma unroll
+            for (int i = 0; i < MU; ++i)
+                if (p0 + i * stride < HW) rz[i] = *(const uint4*)((const T*)a.z[b] + ((long long)n * HW + p0 + i * stride) * C + cg * EPV);
+#pragma unroll
+            for (int i = 0; i < MU; ++i) {
+                if (p0 + i * stride >= HW) break;
+                float fu[EPV], fv[EPV];
+                Vec16<T>::unpack(ru[i], fu);
+                Vec16<T>::unpack(rz[i], fv);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) fu[e] = fmaf(A[e], fu[e], fmaf(B[e], fv[e], D[e]));
+                *(uint4*)((T*)a.dz[b] + ((long long)n * HW + p0 + i * stride) * C + cg * EPV) = Vec16<T>::pack(fu);
+            }
+        }
+    }
+}
+
+__global__ void dgb_store_multi_kernel(GnMultiArgs a, const double* __restrict__ acc0, size_t acc_stride, int N, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const double* dgb = acc0 + b * acc_stride + (size_t)N * C * 2;
+    if (c < C) { a.dgamma[b][c] = (float)dgb[c * 2]; a.dbeta[b][c] = (float)dgb[c * 2 + 1]; }
+}
+
 // ---------------------------------------------------------------------------------------------
 static int img_grid(long long HW, int PL, int N) {
     long long g = (HW + PL - 1) / PL;
@@ -297,6 +458,44 @@ extern "C" int unet_gn_bwd(int dtype, const void* u, const void* z, void* dz, in
     else hipLaunchKernelGGL((affine2_kernel<float>), grid, dim3(256), 0, s, (const float*)u, (const float*)z, (float*)dz, cA, cB, cD, HW, C);
     UNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(dgb_store_kernel, dim3((C + 255) / 256), dim3(256), 0, s, dgb, dgamma, dbeta, C);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+// GroupNorm backward of nb branches that share the upstream gradient u (the per-branch arithmetic of unet_gn_bwd).
+// acc_ws: nb * (N*C*2 + C*2) doubles; coef_ws: nb * 3*N*C floats.
+extern "C" int unet_gn_bwd_multi(int dtype, int nb, const void* u, const void* const* z, void* const* dz, int N, long long HW, int C, int groups,
+                                 const float* const* gamma, const float* const* mean, const float* const* invstd,
+                                 float* const* dgamma, float* const* dbeta, double* acc_ws, float* coef_ws, void* stream) {
+    if (ccheck(dtype, C, "gn_bwd_multi")) return -1;
+    UNET_CHECK(nb >= 1 && nb <= MAX_BRANCH, "gn_bwd_multi: 1..%d branches", MAX_BRANCH);
+    UNET_CHECK(groups > 0 && C % groups == 0 && N > 0 && HW > 0, "gn_bwd_multi: bad shape");
+    UNET_CHECK(u && z && dz && gamma && mean && invstd && dgamma && dbeta && acc_ws && coef_ws, "gn_bwd_multi: null argument");
+    GnMultiArgs a;
+    for (int b = 0; b < MAX_BRANCH; ++b) {
+        const bool on = b < nb;
+        a.z[b] = on ? z[b] : nullptr; a.dz[b] = on ? dz[b] : nullptr; a.gamma[b] = on ? gamma[b] : nullptr;
+        a.mean[b] = on ? mean[b] : nullptr; a.invstd[b] = on ? invstd[b] : nullptr;
+        a.dgamma[b] = on ? dgamma[b] : nullptr; a.dbeta[b] = on ? dbeta[b] : nullptr;
+        UNET_CHECK(!on || (a.z[b] && a.dz[b] && a.gamma[b] && a.mean[b] && a.invstd[b] && a.dgamma[b] && a.dbeta[b]), "gn_bwd_multi: null branch argument");
+    }
+    a.nb = nb;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t acc_stride = (size_t)N * C * 2 + (size_t)C * 2, coef_stride = (size_t)3 * N * C;
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * acc_stride * nb, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
+    dim3 grid(img_grid(HW, PL, N), N);
+    const size_t lds = (size_t)256 * epv * sizeof(float);
+    if (dtype == UNET_BF16) hipLaunchKernelGGL((multi_pair_reduce_kernel<__bf16>), grid, dim3(256), lds, s, a, (const __bf16*)u, HW, C, acc_ws, acc_stride);
+    else hipLaunchKernelGGL((multi_pair_reduce_kernel<float>), grid, dim3(256), lds, s, a, (const float*)u, HW, C, acc_ws, acc_stride);
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_bwd_finalize_multi_kernel, dim3(N, nb), dim3(256), sizeof(double) * 2 * groups, s, a, acc_ws, acc_stride, N, C, groups,
+                       (double)HW * (C / groups), coef_ws, coef_stride);
+    UNET_LAUNCH_CHECK();
+    if (dtype == UNET_BF16) hipLaunchKernelGGL((multi_affine2_kernel<__bf16>), grid, dim3(256), 0, s, a, (const __bf16*)u, coef_ws, coef_stride, N, HW, C);
+    else hipLaunchKernelGGL((multi_affine2_kernel<float>), grid, dim3(256), 0, s, a, (const float*)u, coef_ws, coef_stride, N, HW, C);
+    UNET_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dgb_store_multi_kernel, dim3((C + 255) / 256, nb), dim3(256), 0, s, a, acc_ws, acc_stride, N, C);
     UNET_LAUNCH_CHECK();
     return 0;
 }

@@ -783,6 +783,38 @@ def gn_bwd(u: Act, z: Act, st: GNState, gamma: torch.Tensor):
     return dz, g[0], g[1]
 
 
+GN_MULTI_MAX = 8
+
+
+def gn_bwd_multi(u: Act, zs, sts, gammas):
+    """GroupNorm backward of the branches of one block (they share u) -> [(dz dense Act, dgamma, dbeta), ...]."""
+    import ctypes
+    nb = len(zs)
+    if not 1 <= nb <= GN_MULTI_MAX:
+        raise UNetHipError(f"gn_bwd_multi: 1..{GN_MULTI_MAX} branches")
+    u.check()
+    z0 = zs[0]
+    for z in zs:
+        z.check()
+        if u.off or z.off or u.ld != u.C or z.ld != z.C or u.C != z.C or u.M != z.M or z.dt != u.dt:
+            raise UNetHipError("gn_bwd_multi: dense tensors of equal shape expected")
+    groups = sts[0].groups
+    if any(st.groups != groups for st in sts):
+        raise UNetHipError("gn_bwd_multi: branches must share the group count")
+    N, C, dev = z0.N, z0.C, z0.buf.device
+    dzs = [dense(z0.N, z0.H, z0.W, C, z0.dt, dev) for _ in zs]
+    g = torch.empty((nb, 2, C), dtype=torch.float32, device=dev)
+    acc = torch.empty(nb * (N * C * 2 + C * 2), dtype=torch.float64, device=dev)
+    coef = torch.empty(nb * 3 * N * C, dtype=torch.float32, device=dev)
+    PA = ctypes.c_void_p * nb
+    check(lib().unet_gn_bwd_multi(z0.dt, nb, _p(u.buf), PA(*[z.buf.data_ptr() for z in zs]), PA(*[d.buf.data_ptr() for d in dzs]),
+                                  N, z0.H * z0.W, C, groups, PA(*[t.data_ptr() for t in gammas]),
+                                  PA(*[st.mean.data_ptr() for st in sts]), PA(*[st.invstd.data_ptr() for st in sts]),
+                                  PA(*[g[b, 0].data_ptr() for b in range(nb)]), PA(*[g[b, 1].data_ptr() for b in range(nb)]),
+                                  _p(acc), _p(coef), _stream()), "gn_bwd_multi")
+    return [(dzs[b], g[b, 0], g[b, 1]) for b in range(nb)]
+
+
 def fold_asymm(k, w_sq, w_ve, w_ho, bn_sq, bn_ve, bn_ho, eps=1e-5, sqrt="ieee"):
     """One AsymmConvBlock -> (weight (O,I,k,k), bias (O)); bn_* = (weight, bias, running_mean, running_var).
     sqrt="ieee": std = correctly rounded sqrt(running_var + eps) on the device (reproducible everywhere);

@@ -119,10 +119,17 @@ class RepUNetEngine(UNetEngine):
                 outs = (ops.dense(y.N, y.H, y.W, split_f, dt, dev), ops.dense(y.N, y.H, y.W, Cin - split_f, dt, dev))
             else:
                 outs = (ops.dense(y.N, y.H, y.W, Cin, dt, dev),)
+        gn = None
+        if self.norm == "group":                # every branch's GroupNorm backward in one reduction + one apply pass (they share u)
+            gammas = [P[bnp + ".weight"].detach() for _, bnp, _, _ in rec.names]
+            if len(rec.zs) <= ops.GN_MULTI_MAX:
+                gn = ops.gn_bwd_multi(u, rec.zs, rec.sts, gammas)
+            else:
+                gn = [ops.gn_bwd(u, z, st, g_) for z, st, g_ in zip(rec.zs, rec.sts, gammas)]
         for bi, (z, st, (wname, bnp, kh, kw)) in enumerate(zip(rec.zs, rec.sts, rec.names)):
             gamma = P[bnp + ".weight"].detach()
-            if self.norm == "group":
-                dz, dg, db = ops.gn_bwd(u, z, st, gamma)
+            if gn is not None:
+                dz, dg, db = gn[bi]
             else:
                 dz = ops.dense(z.N, z.H, z.W, z.C, dt, dev)
                 dg, db, _ = ops.bn_relu_bwd(u, z, dz, st, ws, relu=False, want_dbias=False)
