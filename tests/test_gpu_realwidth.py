@@ -105,6 +105,19 @@ def test_conv5x5_and_asymmetric_real_widths(dev, dt, k, shape):
     ops.conv_fwd(dza, wd, None, dxb, kh, kw, Cout, Cin, accumulate=True)
     close(from_act(dxb), base + x.grad, dt, "conv dgrad, accumulated")
 
+    # weight gradient the way rep_engine issues it: up to 9 taps in one launch, a 5x5 row-wise (bf16: 2x5 + 2x5 + 1x5)
+    ws = ops.Workspace(dev)
+    if kh * kw <= 9:
+        dw = ops.conv_wgrad(dza, xa, kh, kw, ws)[0]
+    else:
+        dw = torch.empty((Cout, Cin, kh * kw), dtype=torch.float32, device=dev)
+        r = 0
+        while r < kh:
+            nr = 2 if (dt == 1 and r + 1 < kh) else 1
+            ops.conv_wgrad(dza, xa, nr, kw, ws, dw=dw, pad_h=kh // 2 - r, pad_w=kw // 2, dw_taps=kh * kw, dw_tap0=r * kw)
+            r += nr
+    close(dw.view(Cout, Cin, kh, kw).cpu(), w.grad, dt, "conv wgrad", f32_out=True)
+
 
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("shape", REAL_CONV)

@@ -195,45 +195,59 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
     }
 }
 
-// The same for a 9-tap gradient.  A thread owns one (o, i) pair and all nine taps: nine independent coalesced loads per
-// split, and its nine results leave as 36 contiguous bytes.  Small layers have few (o, i) pairs but many splits (64 x 64
-// weights: 4096 pairs, 256 splits = 16 workgroups walking 256 slabs each), so KL lanes share a pair: lane kl sums splits
+// The same with a thread owning one (o, i) pair and all NT taps of the launch: NT independent coalesced loads per split, and
+// its NT results leave as 4*NT contiguous bytes.  Small layers have few (o, i) pairs but many splits (64 x 64 weights:
+// 4096 pairs, 256 splits = 16 workgroups walking 256 slabs each), so KL lanes share a pair: lane kl sums splits
 // kl, kl + KL, ... in order, lane 0 then adds the KL partials in lane order - a fixed order, bitwise reproducible.
-template <int KL>
+// (NT = 9: the 3x3 gradients; 3 / 5 / 10: the k x 1, 1 x k branches and the row pieces of a 5x5, models/reparm_unet.py:55-61.)
+template <int KL, int NT>
 __global__ __launch_bounds__(256) void wgrad_reduce9_kernel(const float* __restrict__ slab, float* __restrict__ out,
                                                             int nsplit, int O, int I, int accumulate, int out_taps, int out_tap0) {
     constexpr int EL = 256 / KL;                         // (o, i) pairs per workgroup
-    __shared__ float part[KL > 1 ? KL : 1][EL][9];
-    const size_t OI = (size_t)O * I, total = 9 * OI;
+    __shared__ float part[KL > 1 ? KL : 1][EL][NT];
+    const size_t OI = (size_t)O * I, total = NT * OI;
     const int el = threadIdx.x % EL, kl = threadIdx.x / EL;
     for (size_t e0 = (size_t)blockIdx.x * EL; e0 < OI; e0 += (size_t)gridDim.x * EL) {
         const size_t e = e0 + el;
-        float s[9];
+        float s[NT];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) s[t] = 0.f;
+        for (int t = 0; t < NT; ++t) s[t] = 0.f;
         if (e < OI) {
             for (int k = kl; k < nsplit; k += KL) {
                 const float* p = slab + (size_t)k * total + e;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) s[t] += p[(size_t)t * OI];
+                for (int t = 0; t < NT; ++t) s[t] += p[(size_t)t * OI];
             }
         }
         if (KL > 1) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) part[kl][el][t] = s[t];
+            for (int t = 0; t < NT; ++t) part[kl][el][t] = s[t];
             __syncthreads();
             if (kl == 0) {
                 for (int q = 1; q < KL; ++q)
 #pragma unroll
-                    for (int t = 0; t < 9; ++t) s[t] += part[q][el][t];
+                    for (int t = 0; t < NT; ++t) s[t] += part[q][el][t];
             }
             __syncthreads();
         }
         if (kl == 0 && e < OI) {
             float* d = out + e * out_taps + out_tap0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) d[t] = accumulate ? d[t] + s[t] : s[t];
+            for (int t = 0; t < NT; ++t) d[t] = accumulate ? d[t] + s[t] : s[t];
         }
+    }
+}
+
+template <int NT>
+static void launch_reduce_taps(const float* slab, float* dw, int nsplit, int Cout, int Cin, int accumulate, int dw_taps, int dw_tap0, hipStream_t s) {
+    const size_t OI = (size_t)Cout * Cin;
+    if (OI < 262144 && nsplit >= 16) {                // fewer than 1024 workgroups of pairs: share each pair among 8 lanes
+        const int b = (int)((OI + 31) / 32);
+        hipLaunchKernelGGL((wgrad_reduce9_kernel<8, NT>), dim3(b), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
+    } else {
+        int b = (int)((OI + 255) / 256);
+        if (b > 4096) b = 4096;
+        hipLaunchKernelGGL((wgrad_reduce9_kernel<1, NT>), dim3(b), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
     }
 }
 
@@ -292,9 +306,10 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
     UNET_CHECK(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && xoff % 8 == 0 && lddz % 8 == 0 && dzoff % 8 == 0,
                "channel counts/strides/offsets must be multiples of 8");
     UNET_CHECK(xoff + Cin <= ldx && dzoff + Cout <= lddz, "channel slice exceeds pixel stride");
-    // pad_h/pad_w may be any integers: a 5x5 weight grad is issued as five 1x5 launches with
-    // pad_h = 2 - row, each filling taps [dw_tap0, dw_tap0 + kh*kw) of the dw_taps-tap gradient
-    UNET_CHECK(kh * kw <= 9, "wgrad handles at most 9 taps per launch; split larger kernels by rows");
+    // pad_h/pad_w may be any integers: a 5x5 weight grad is issued row-wise (bf16: 2x5 + 2x5 + 1x5 launches, fp32: five 1x5)
+    // with pad_h = 2 - first row, each filling taps [dw_tap0, dw_tap0 + kh*kw) of the dw_taps-tap gradient
+    UNET_CHECK(kh * kw <= 10, "wgrad handles at most 10 taps per launch; split larger kernels by rows");
+    UNET_CHECK(!(kh == 2 && kw == 5) || dtype == UNET_BF16, "the 2x5 row pair is a bf16 instantiation");
     UNET_CHECK(dw_tap0 >= 0 && dw_tap0 + kh * kw <= dw_taps, "tap window outside the gradient tensor");
     UNET_CHECK(N > 0 && Hout > 0 && Wout > 0, "empty wgrad problem");
     UNET_CHECK((size_t)Hin * Win * ldx < (1ull << 31) && (size_t)Hout * Wout * lddz < (1ull << 31), "image exceeds 2^31 elements");
@@ -315,18 +330,12 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
     const size_t total = (size_t)kh * kw * Cout * Cin;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    if (kh * kw == 9) {
-        const size_t OI = (size_t)Cout * Cin;
-        if (OI < 262144 && nsplit >= 16) {                // fewer than 1024 workgroups of pairs: share each pair among 8 lanes
-            int b9 = (int)((OI + 31) / 32);
-            hipLaunchKernelGGL(wgrad_reduce9_kernel<8>, dim3(b9), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
-        } else {
-            int b9 = (int)((OI + 255) / 256);
-            if (b9 > 4096) b9 = 4096;
-            hipLaunchKernelGGL(wgrad_reduce9_kernel<1>, dim3(b9), dim3(256), 0, s, slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0);
-        }
-    } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, nsplit, kh * kw, Cout, Cin, accumulate, dw_taps, dw_tap0);
+    switch (kh * kw) {
+        case 9: launch_reduce_taps<9>(slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0, s); break;
+        case 3: launch_reduce_taps<3>(slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0, s); break;
+        case 5: launch_reduce_taps<5>(slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0, s); break;
+        case 10: launch_reduce_taps<10>(slab, dw, nsplit, Cout, Cin, accumulate, dw_taps, dw_tap0, s); break;
+        default: hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, slab, dw, nsplit, kh * kw, Cout, Cin, accumulate, dw_taps, dw_tap0);
     }
     UNET_LAUNCH_CHECK();
     return 0;

@@ -260,14 +260,15 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
         // row r (two register sets), so an LDS round trip is covered by a whole row of matrix work.
         uint4 fa[2][WM];
         load_a(0, fa[0]);
-        if constexpr (SH == 1 && KH == 3) {
+        if constexpr (SH == 1 && (KH == 3 || (KH == 2 && KW == 5))) {
             // The x fragment of (row r, tap kh, kw) is halo row r + kh shifted by kw: consecutive rows share two
             // of their three halo rows.  Keep a ring of four halo rows in registers and read only the new one
             // per K-step (3 fragments instead of 9: the LDS read traffic of the loop drops from 22 to 10
             // transposed reads per 18 MFMAs).
             // The ring holds THREE rows: row r's slot is free once the kh = 0 taps of step r have been issued, and the
             // row the step after next needs (r + 3) is requested into it right there, under the step's other 12 MFMAs.
-            uint4 hf[3][KW][WN];
+            // (KH = 2, the two-row pieces a 5x5 gradient is issued in: a ring of two rows.)
+            uint4 hf[KH][KW][WN];
             auto load_h = [&](int row, uint4 (*dst)[WN]) {
 #pragma unroll
                 for (int kw = 0; kw < KW; ++kw)
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
                     for (int j = 0; j < WN; ++j)
                         dst[kw][j] = tr_frag2(img + row * (HWD * REC) + b_lo[kw][j], img + row * (HWD * REC) + b_hi[kw][j]);
             };
-            load_h(0, hf[0]); load_h(1, hf[1]); load_h(2, hf[2]);
+#pragma unroll
+            for (int k = 0; k < KH; ++k) load_h(k, hf[k]);
 #pragma unroll
             for (int r = 0; r < TH; ++r) {
                 if (r + 1 < TH) load_a(r + 1, fa[(r + 1) & 1]);
@@ -287,11 +289,11 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
 #pragma unroll
                         for (int j = 0; j < WN; ++j)
                             acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, hf[(r + t2 / KW) % 3][t2 % KW][j]),
+                                __builtin_bit_cast(bf16x8, fa[r & 1][i]), __builtin_bit_cast(bf16x8, hf[(r + t2 / KW) % KH][t2 % KW][j]),
                                 acc[t2][i][j], 0, 0, 0);
                     if (t2 == KW - 1) {
                         __builtin_amdgcn_sched_barrier(0);
-                        if (r + 1 < TH) load_h(r + 3, hf[r % 3]);
+                        if (r + 1 < TH) load_h(r + KH, hf[r % KH]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -394,6 +396,7 @@ int dispatch_wgrad2(int kh, int kw, int sh, const WgradArgs& a, hipStream_t s, i
     if (kh == 1 && kw == 3) return launch_wgrad2<1, 3, 1, 2, 8, true>(a, s, nsplit);
     if (kh == 5 && kw == 1) return launch_wgrad2<5, 1, 1, 2, 8, true>(a, s, nsplit);
     if (kh == 1 && kw == 5) return launch_wgrad2<1, 5, 1, 2, 8, true>(a, s, nsplit);
+    if (kh == 2 && kw == 5) return launch_wgrad2<2, 5, 1, 2, 8, true>(a, s, nsplit);      // two rows of a 5x5 gradient per launch
     unet_set_error("unsupported wgrad kernel %dx%d stride %d", kh, kw, sh);
     return -1;
 }

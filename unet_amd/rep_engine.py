@@ -142,8 +142,11 @@ class RepUNetEngine(UNetEngine):
                 grads[wname] = ops.conv_wgrad(dz, rec.xin, kh, kw, ws)[0].view_as(w)
             else:
                 dw = torch.empty_like(w, dtype=torch.float32)
-                for r in range(kh):
-                    ops.conv_wgrad(dz, rec.xin, 1, kw, ws, dw=dw, pad_h=kh // 2 - r, pad_w=kw // 2, dw_taps=kh * kw, dw_tap0=r * kw)
+                r = 0
+                while r < kh:               # bf16: two kernel rows per launch (2x5 instantiation), the odd row alone
+                    nr = 2 if (dt == ops.BF16 and kw == 5 and r + 1 < kh) else 1
+                    ops.conv_wgrad(dz, rec.xin, nr, kw, ws, dw=dw, pad_h=kh // 2 - r, pad_w=kw // 2, dw_taps=kh * kw, dw_tap0=r * kw)
+                    r += nr
                 grads[wname] = dw
             if outs is not None:
                 wd = self.packed(wname, w, 1, dt)
