@@ -168,7 +168,9 @@ int unet_affine_act_pool(int dtype, int relu, const void* z, int ldz, int zoff, 
                          int N, int H, int W, int C, void* stream);
 /* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z.
  * relu: bit 0 = ReLU after the norm; bit 1 = frozen statistics (model.eval() with gradients enabled: mean / invstd are
- * the running statistics and carry no gradient): dz = scale*dy', dgamma = sum dy'*(z-mean)*invstd, dbeta = sum dy'. */
+ * the running statistics and carry no gradient): dz = scale*dy', dgamma = sum dy'*(z-mean)*invstd, dbeta = sum dy'.
+ * acc_ws: 3*C doubles.  c1c2_ws is no longer used (the finalize between the two passes now runs inside the second) and may
+ * be NULL; the argument stays so that existing callers keep working. */
 int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
                      void* dz, int ldo, int ooff,
                      const float* scale, const float* shift, const float* mean, const float* invstd,

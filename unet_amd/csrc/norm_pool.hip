@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
                                                            T* __restrict__ dz, int ldo, int ooff,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           const double* __restrict__ sums, double count, int frozen,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                            long long M, int C, double* __restrict__ dbias_acc) {
     constexpr int EPV = TT<T>::EPV;
     ChanMap m; m.init<T>(C);
@@ -289,7 +290,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const int c = m.cg * EPV + e;
-            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c]; k1[e] = c1[c]; k2[e] = c2[c];
+            sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+            // pass 1's sums (S1, S2) finalised here instead of in a launch of their own: dgamma = S2, dbeta = S1,
+            // c1 = S1/n, c2 = S2/n (the arithmetic of bn_bwd_finalize_kernel); workgroup 0 writes the two gradients
+            const double s1 = sums[c * 2], s2 = sums[c * 2 + 1];
+            k1[e] = frozen ? 0.f : (float)(s1 / count);
+            k2[e] = frozen ? 0.f : (float)(s2 / count);
+            if (blockIdx.x == 0 && m.pl == 0) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
         }
         const long long stride = (long long)gridDim.x * m.PL;
         for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * STREAM_U) {
@@ -660,7 +667,7 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
                             long long M, int C, void* stream) {
     if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
     UNET_CHECK(scale && shift && mean && invstd, "bn_relu_bwd: scale / shift / mean / invstd must not be NULL");
-    UNET_CHECK(dy && z && dz && dgamma && dbeta && c1c2_ws && acc_ws, "bn_relu_bwd: null argument");
+    UNET_CHECK(dy && z && dz && dgamma && dbeta && acc_ws, "bn_relu_bwd: null argument");
     const int frozen = (relu >> 1) & 1;
     relu &= 1;
     UNET_CHECK(ldd % 8 == 0 && doff % 8 == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0,
@@ -670,14 +677,12 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     const int grid = grid_for(M, PL);
     if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
     const size_t lds1 = reduce_lds_bytes(C / epv, 2 * epv), lds2 = reduce_lds_bytes(C / epv, epv);
-    float* c1 = c1c2_ws; float* c2 = c1c2_ws + C;
+    (void)c1c2_ws;            // the finalize that filled it now lives in the apply pass
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
 #define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
-#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, c1, c2, M, C, dbacc)
+#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, acc_ws, (double)M, frozen, dgamma, dbeta, M, C, dbacc)
     if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
     else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
-    UNET_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws, (double)M, C, frozen, dgamma, dbeta, c1, c2);
     UNET_LAUNCH_CHECK();
     if (dtype == UNET_BF16) { if (relu) LAUNCH_A(__bf16, true); else LAUNCH_A(__bf16, false); }
     else { if (relu) LAUNCH_A(float, true); else LAUNCH_A(float, false); }
