@@ -320,6 +320,8 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     const int eh = (Hin + 2 * pad_h - kh) / stride_h + 1, ew = Win + 2 * pad_w - kw + 1;
     UNET_CHECK(eh == Hout && ew == Wout, "output %dx%d does not match conv geometry %dx%d", Hout, Wout, eh, ew);
     UNET_CHECK(x != nullptr && w != nullptr && y != nullptr, "conv_fwd: null pointer argument");
+    // statistics are those of the conv's own result; an accumulating launch (flags bit 0, the summed branch dgrads) has none to offer
+    UNET_CHECK((flags & 1) == 0 || stats == nullptr, "conv_fwd: statistics and accumulation (flags bit 0) exclude each other");
     ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = y; a.stats = stats;
     a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.ldx = ldx; a.xoff = xoff;
