@@ -85,8 +85,9 @@ int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, i
  * First layer, in_channels = 1, 3x3 (models/unet.py:30 + :11-12).  Forward: unet_conv_first_fwd with z = NULL writes only the
  * statistics rows; after unet_bn_finalize, unet_first_bn_act computes y = act(scale*conv(x)+shift) in one pass: the pre-norm
  * tensor is never stored.  Backward: unet_first_bn_relu_bwd = unet_bn_relu_bwd with that tensor recomputed from x, plus the
- * conv's weight gradient dw (Cout,1,3,3) accumulated from the dz it holds in registers (dz is not stored: the first conv has
- * no input gradient).  relu bits as unet_bn_relu_bwd.  acc_ws: 12*Cout doubles. */
+ * conv's weight gradient dw (Cout,1,3,3) (dz is not stored: the first conv has no input gradient).  ONE pass over dy: dz is
+ * affine in (dy', z) with per-channel coefficients, so dw follows from sum dy'*patch (accumulated next to the BN sums) and
+ * the 3x3 patch moments of x (a small kernel of their own).  relu bits as unet_bn_relu_bwd.  acc_ws: 12*Cout + 64 doubles. */
 int unet_first_bn_act(int dtype, int relu, const float* x, const float* w, const float* bias,
                       const float* scale, const float* shift, void* y, int ldy, int yoff,
                       int N, int H, int W, int Cout, void* stream);

@@ -68,9 +68,13 @@ def test_first_layer_fused_vs_torch(dev, dt, shape):
     dz = ops.dense(N, H, W, Cout, dt, dev)
     dg2, db2, dbias2 = ops.bn_relu_bwd(to_act(dyv, dt, dev), zt, dz, st, ws)
     dw2 = ops.conv_first_wgrad(dz, xh, 3, 3, ws)
-    # the two paths add the same terms in different orders (column strips vs strided pixels): fp32 summation noise only
-    for a_, b_, what in ((dg, dg2, "dgamma"), (db_, db2, "dbeta"), (dw, dw2, "dW")):
+    # the two paths add the same terms in different orders (column strips vs strided pixels): fp32 summation noise only.
+    # dW: the fused path derives it in ONE pass from sum dy'*patch and the patch moments of x (dz is affine in dy' and z), so
+    # in bf16 it skips two roundings the separate kernels make (z and dz to the storage type before the sum): the two differ
+    # by that rounding noise, 2^-9 per element averaged over the pixels (fp32: no such roundings, same 1e-4 bound)
+    for a_, b_, what in ((dg, dg2, "dgamma"), (db_, db2, "dbeta")):
         assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max()), what
+    assert float((dw - dw2).abs().max()) <= (1e-4 if dt == 0 else 2 ** -8) * float(dw2.abs().max()), "dW"
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -156,4 +160,9 @@ def test_engine_with_and_without_fused_edges(dev, mode):
             a, b = outs[0][1][k], outs[1][1][k]
             if k.endswith("double_conv.0.bias") or k.endswith("double_conv.3.bias"):
                 continue                                     # noise-only gradients in train mode
+            if mode == "bf16" and k == "downs.0.double_conv.0.weight":
+                # the fused first layer takes dW from sum dy'*patch and the patch moments of x in one pass: it skips the
+                # storage-type roundings of z and dz that the separate kernels put into this sum (see the test above)
+                assert float((a - b).abs().max()) <= 2 ** -8 * float(b.abs().max()), k
+                continue
             torch.testing.assert_close(a, b, rtol=2e-4 if mode == "bf16" else 2e-5, atol=1e-6 * float(b.abs().max()) + 1e-9, msg=k)

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void first1_bn_act_kernel(const float* __restr
 //   PASS 1: S1 = sum dy', S2 = sum dy' * xhat                      -> acc[C][2]
 //   PASS 2: dz = round_T(scale * (dy' - c1 - xhat*c2)); sum dz     -> dbias acc[C]
 //           dW[co][tap] = sum_p dz[p][co] * x[p + tap]             -> wacc[C][9]   (dz is not stored)
+//   PASS 3: pass 1 plus A[co][tap] = sum_p dy'[p][co] * x[p + tap] -> wacc[C][9]: everything the SINGLE-PASS form needs
+//           from the gradient (unet_first_bn_relu_bwd below); passes 1 + 2 remain as the reference form for the tests.
 template <typename T, bool RELU, int PASS>
 __global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict__ dy, int ldd, int doff,
                                                             const float* __restrict__ x, const float* __restrict__ w,
@@ -95,9 +97,9 @@ __global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict_
     float part[2 * EPV];
 #pragma unroll
     for (int i = 0; i < 2 * EPV; ++i) part[i] = 0.f;
-    float pw[PASS == 2 ? 9 : 1][EPV];
+    float pw[PASS >= 2 ? 9 : 1][EPV];
 #pragma unroll
-    for (int t = 0; t < (PASS == 2 ? 9 : 1); ++t)
+    for (int t = 0; t < (PASS >= 2 ? 9 : 1); ++t)
 #pragma unroll
         for (int e = 0; e < EPV; ++e) pw[t][e] = 0.f;
     if (m.active) {
@@ -143,9 +145,17 @@ __global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict_
                     const float z = round_to<T>(v);
                     const float d = (!RELU || fmaf(z, sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
                     const float xh = (z - mu[e]) * is[e];
-                    if constexpr (PASS == 1) {
+                    if constexpr (PASS == 1 || PASS == 3) {
                         part[e] += d;
                         part[EPV + e] += d * xh;
+                        if constexpr (PASS == 3) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                pw[k][e] = fmaf(d, ra[k], pw[k][e]);
+                                pw[3 + k][e] = fmaf(d, rb[k], pw[3 + k][e]);
+                                pw[6 + k][e] = fmaf(d, rc[k], pw[6 + k][e]);
+                            }
+                        }
                     } else {
                         const float dz = round_to<T>(sc[e] * (d - k1[e] - xh * k2[e]));
                         part[e] += dz;
@@ -163,13 +173,14 @@ __global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict_
             }
         }
     }
-    if constexpr (PASS == 1) {
-        block_reduce_to_acc<2 * EPV>(m, part, EPV, Cout, acc, 2);
-    } else {
+    if constexpr (PASS == 1 || PASS == 3) block_reduce_to_acc<2 * EPV>(m, part, EPV, Cout, acc, 2);
+    if constexpr (PASS == 2) {
         float p1[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) p1[e] = part[e];
         block_reduce_to_acc<EPV>(m, p1, EPV, Cout, acc, 1);
+    }
+    if constexpr (PASS >= 2) {
         // weight-gradient partials, one tap at a time through the same reduction (acc row stride 9: wacc[c*9 + t])
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -187,6 +198,100 @@ static __global__ void first1_store_kernel(const double* __restrict__ dbacc, con
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < C && dbias != nullptr) dbias[i] = (float)dbacc[i];
     if (i < C * 9) dw[i] = (float)wacc[i];
+}
+
+// Patch moments of the 1-channel input: s[t] = sum_p u_p[t], R[t][t'] = sum_p u_p[t] u_p[t'] (t <= t'), n = pixels, with
+// u_p the zero-padded 3x3 patch of pixel p.  mom[55] fp64, accumulated with one atomic per value and workgroup.
+__global__ __launch_bounds__(256) void first1_moments_kernel(const float* __restrict__ x, int N, int H, int W, double* __restrict__ mom) {
+    constexpr int PX = 4;                      // consecutive pixels of a row per thread: 18 loads for 4 patches
+    __shared__ float part[4][55];
+    const int Wg = (W + PX - 1) / PX;
+    const long long groups = (long long)N * H * Wg;
+    float s[9], r[45], cnt = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 45; ++t) r[t] = 0.f;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < groups; q += (long long)gridDim.x * 256) {
+        const int wg = (int)(q % Wg);
+        const long long t1 = q / Wg;
+        const int h = (int)(t1 % H), n = (int)(t1 / H);
+        const int w0 = wg * PX;
+        const float* xi = x + (long long)n * H * W;
+        float win[3][PX + 2];
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr) {
+            const int hh = h + dr - 1;
+            const bool rowok = (unsigned)hh < (unsigned)H;
+            const float* xr = xi + (long long)hh * W;
+#pragma unroll
+            for (int j = 0; j < PX + 2; ++j) {
+                const int ww = w0 + j - 1;
+                win[dr][j] = (rowok && (unsigned)ww < (unsigned)W) ? xr[ww] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int px = 0; px < PX; ++px) {
+            if (w0 + px >= W) break;
+            cnt += 1.f;
+            float u[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) u[t] = win[t / 3][px + t % 3];
+            int k = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                s[t] += u[t];
+#pragma unroll
+                for (int t2 = t; t2 < 9; ++t2) { r[k] = fmaf(u[t], u[t2], r[k]); ++k; }
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 55; ++i) {
+        float v = i < 9 ? s[i] : (i < 54 ? r[i < 54 ? i - 9 : 0] : cnt);
+        for (int st = 32; st >= 1; st >>= 1) v += __shfl_xor(v, st);
+        if (lane == 0) part[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 55)
+        atomicAdd(&mom[threadIdx.x], (double)part[0][threadIdx.x] + (double)part[1][threadIdx.x] + (double)part[2][threadIdx.x] + (double)part[3][threadIdx.x]);
+}
+
+// Everything the first layer's backward returns, from pass 3's sums and the input's patch moments.  With d = dy' (ReLU-masked),
+// z = w.u + b, xhat = (z - mu)*is and dz = sc*(d - c1 - xhat*c2) (c1 = S1/n, c2 = S2/n; both 0 with frozen statistics):
+//   dW[c][t]  = sum_p dz u[t] = sc*(A[t] - c1 s[t]) - sc*c2*is*(B[t] - mu s[t]),   B[t] = sum_p z u[t] = sum_t' w[t'] R[t'][t] + b s[t]
+//   dbias[c]  = sum_p dz      = sc*(S1 - n c1) - sc*c2*is*(w.s + n b - n mu)        (rounding noise in train mode, as in the reference)
+// so the second pass over dy (which existed only to multiply dz with the patches) is not needed.  B uses the unrounded z; in bf16
+// mode the stored-type rounding of z (2^-9 relative, unbiased) averages out of a sum over all pixels.  fp64 throughout.
+__global__ __launch_bounds__(256) void first1_bwd_finalize_kernel(const double* __restrict__ acc, const double* __restrict__ wacc,
+                                                                  const double* __restrict__ mom, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, const float* __restrict__ scale,
+                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                  int frozen, int C, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dbias, float* __restrict__ dw) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = mom[54];
+    const double S1 = acc[c * 2], S2 = acc[c * 2 + 1];
+    dgamma[c] = (float)S2;
+    dbeta[c] = (float)S1;
+    const double c1 = frozen ? 0.0 : (double)(float)(S1 / n), c2 = frozen ? 0.0 : (double)(float)(S2 / n);   // the fp32 coefficients the two-pass form applies
+    const double sc = scale[c], is = invstd[c], mu = mean[c], b = bias != nullptr ? (double)bias[c] : 0.0;
+    double wc[9], ws = 0.0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wc[t] = (double)w[c * 9 + t]; ws += wc[t] * mom[t]; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        double B = b * mom[t];
+#pragma unroll
+        for (int t2 = 0; t2 < 9; ++t2) {
+            const int lo = t2 < t ? t2 : t, hi = t2 < t ? t : t2;
+            B += wc[t2] * mom[9 + lo * 9 - lo * (lo - 1) / 2 + (hi - lo)];     // row lo of the upper triangle starts at 9 + sum_{i<lo} (9 - i)
+        }
+        dw[c * 9 + t] = (float)(sc * (wacc[c * 9 + t] - c1 * mom[t]) - sc * c2 * is * (B - mu * mom[t]));
+    }
+    if (dbias != nullptr) dbias[c] = (float)(sc * (S1 - n * c1) - sc * c2 * is * (ws + n * b - n * mu));
 }
 
 // =================================================================================================
@@ -409,7 +514,7 @@ extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int l
                                       const float* x, const float* w, const float* bias,
                                       const float* scale, const float* shift, const float* mean, const float* invstd,
                                       float* dgamma, float* dbeta, float* dbias /* nullable */, float* dw /* [Cout][1][3][3] */,
-                                      float* c1c2_ws /* 2*Cout floats */, double* acc_ws /* 12*Cout doubles */,
+                                      float* c1c2_ws /* 2*Cout floats */, double* acc_ws /* 12*Cout + 64 doubles */,
                                       int N, int H, int W, int Cout, void* stream) {
     if (ef_check(dtype, Cout, "first_bn_relu_bwd")) return -1;
     UNET_CHECK(dy && x && w && scale && shift && mean && invstd && dgamma && dbeta && dw && c1c2_ws && acc_ws, "first_bn_relu_bwd: null argument");
@@ -418,25 +523,40 @@ extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int l
     relu &= 1;
     hipStream_t s = (hipStream_t)stream;
     const int epv = dtype == UNET_BF16 ? 8 : 4, G = Cout / epv;
-    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 12 * Cout, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * (12 * Cout + 64), s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
     double* dbacc = acc_ws + 2 * Cout;
     double* wacc = acc_ws + 3 * Cout;
+    double* mom = acc_ws + 12 * Cout;
     float* c1 = c1c2_ws; float* c2 = c1c2_ws + Cout;
     const long long tiles = (long long)N * ((H + FIRST_R - 1) / FIRST_R) * ((W + 256 / G - 1) / (256 / G));
     const int grid = (int)(tiles < MAX_GRID ? tiles : MAX_GRID);
     const size_t lds1 = reduce_lds_bytes(G, 2 * epv), lds2 = reduce_lds_bytes(G, epv);
-#define LP1(T, R) hipLaunchKernelGGL((first1_bn_bwd_kernel<T, R, 1>), dim3(grid), dim3(256), lds1, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, nullptr, nullptr, N, H, W, Cout, acc_ws, nullptr)
-#define LP2(T, R) hipLaunchKernelGGL((first1_bn_bwd_kernel<T, R, 2>), dim3(grid), dim3(256), lds2, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, c1, c2, N, H, W, Cout, dbacc, wacc)
-    if (dtype == UNET_BF16) { if (relu) LP1(__bf16, true); else LP1(__bf16, false); }
-    else { if (relu) LP1(float, true); else LP1(float, false); }
+    // UNET_AMD_FIRST_BWD_2PASS=1: the two-pass form (dz recomputed and multiplied with the patches in a second pass), for A/B runs
+    static const bool two_pass = [] { const char* e = getenv("UNET_AMD_FIRST_BWD_2PASS"); return e && atoi(e) != 0; }();
+#define LP(T, R, P, L, A1, A2, A3, A4) hipLaunchKernelGGL((first1_bn_bwd_kernel<T, R, P>), dim3(grid), dim3(256), L, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, A1, A2, N, H, W, Cout, A3, A4)
+#define LPD(P, L, A1, A2, A3, A4) do { if (dtype == UNET_BF16) { if (relu) LP(__bf16, true, P, L, A1, A2, A3, A4); else LP(__bf16, false, P, L, A1, A2, A3, A4); } \
+                                       else { if (relu) LP(float, true, P, L, A1, A2, A3, A4); else LP(float, false, P, L, A1, A2, A3, A4); } } while (0)
+    if (!two_pass) {
+        const long long groups = (long long)N * H * ((W + 3) / 4);
+        long long mg = (groups + 255) / 256;
+        if (mg > 256) mg = 256;                                     // 55 fp64 atomics per workgroup: keep them few
+        hipLaunchKernelGGL(first1_moments_kernel, dim3((unsigned)mg), dim3(256), 0, s, x, N, H, W, mom);
+        UNET_LAUNCH_CHECK();
+        LPD(3, lds1, (const float*)nullptr, (const float*)nullptr, acc_ws, wacc);
+        UNET_LAUNCH_CHECK();
+        hipLaunchKernelGGL(first1_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, wacc, mom, w, bias, scale, mean, invstd,
+                           frozen, Cout, dgamma, dbeta, dbias, dw);
+        UNET_LAUNCH_CHECK();
+        return 0;
+    }
+    LPD(1, lds1, (const float*)nullptr, (const float*)nullptr, acc_ws, (double*)nullptr);
     UNET_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, (double)N * H * W, Cout, frozen, dgamma, dbeta, c1, c2);
     UNET_LAUNCH_CHECK();
-    if (dtype == UNET_BF16) { if (relu) LP2(__bf16, true); else LP2(__bf16, false); }
-    else { if (relu) LP2(float, true); else LP2(float, false); }
+    LPD(2, lds2, (const float*)c1, (const float*)c2, dbacc, wacc);
     UNET_LAUNCH_CHECK();
-#undef LP1
-#undef LP2
+#undef LP
+#undef LPD
     hipLaunchKernelGGL(first1_store_kernel, dim3((Cout * 9 + 255) / 256), dim3(256), 0, s, dbacc, wacc, Cout, dbias, dw);
     UNET_LAUNCH_CHECK();
     return 0;

@@ -364,7 +364,7 @@ def first_bn_relu_bwd(dy: Act, x: torch.Tensor, w: torch.Tensor, bias: Optional[
         raise UNetHipError("first_bn_relu_bwd: shape mismatch")
     if x.dtype != torch.float32 or not x.is_contiguous() or w.dtype != torch.float32 or not w.is_contiguous():
         raise UNetHipError("first_bn_relu_bwd: fp32 contiguous input and weights expected")
-    if 12 * Cout > ws.acc.numel() or 2 * Cout > ws.c1c2.numel():
+    if 12 * Cout + 64 > ws.acc.numel() or 2 * Cout > ws.c1c2.numel():
         raise UNetHipError("first_bn_relu_bwd: workspace too small")
     g = torch.empty((3, Cout), dtype=torch.float32, device=x.device)
     dw = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=x.device)
