@@ -285,18 +285,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
     float part[EPV];
 #pragma unroll
     for (int i = 0; i < EPV; ++i) part[i] = 0.f;
+    // pass 1's sums (S1, S2) finalised here instead of in a launch of their own: dgamma = S2, dbeta = S1, c1 = S1/n, c2 = S2/n
+    // (the arithmetic of bn_bwd_finalize_kernel).  One thread per channel divides (fp64) and the workgroup shares the two
+    // coefficients through LDS -- every thread dividing for its eight channels cost 16 us per launch; workgroup 0 writes the
+    // two gradients.  The LDS area is the block reduction's, which is not in use yet.
+    extern __shared__ float coef[];                      // [2][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double s1 = sums[c * 2], s2 = sums[c * 2 + 1];
+        coef[c] = frozen ? 0.f : (float)(s1 / count);
+        coef[C + c] = frozen ? 0.f : (float)(s2 / count);
+        if (blockIdx.x == 0) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
+    }
+    __syncthreads();
     if (m.active) {
         float sc[EPV], sh[EPV], mu[EPV], is[EPV], k1[EPV], k2[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const int c = m.cg * EPV + e;
             sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
-            // pass 1's sums (S1, S2) finalised here instead of in a launch of their own: dgamma = S2, dbeta = S1,
-            // c1 = S1/n, c2 = S2/n (the arithmetic of bn_bwd_finalize_kernel); workgroup 0 writes the two gradients
-            const double s1 = sums[c * 2], s2 = sums[c * 2 + 1];
-            k1[e] = frozen ? 0.f : (float)(s1 / count);
-            k2[e] = frozen ? 0.f : (float)(s2 / count);
-            if (blockIdx.x == 0 && m.pl == 0) { dgamma[c] = (float)s2; dbeta[c] = (float)s1; }
+            k1[e] = coef[c]; k2[e] = coef[C + c];
         }
         const long long stride = (long long)gridDim.x * m.PL;
         for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * STREAM_U) {
@@ -334,7 +341,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
             }
         }
     }
-    if (dbias_acc != nullptr) block_reduce_to_acc<EPV>(m, part, EPV, C, dbias_acc, 1);
+    if (dbias_acc != nullptr) {
+        __syncthreads();                                 // everyone has read its coefficients out of the shared area
+        block_reduce_to_acc<EPV>(m, part, EPV, C, dbias_acc, 1);
+    }
 }
 
 // plain ReLU backward (no norm): dz = dy * [y > 0]   (RepUNet: ReLU after the branch sum)
@@ -676,7 +686,9 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
     const int grid = grid_for(M, PL);
     if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
-    const size_t lds1 = reduce_lds_bytes(C / epv, 2 * epv), lds2 = reduce_lds_bytes(C / epv, epv);
+    const size_t lds1 = reduce_lds_bytes(C / epv, 2 * epv);
+    size_t lds2 = reduce_lds_bytes(C / epv, epv);
+    if (lds2 < (size_t)2 * C * sizeof(float)) lds2 = (size_t)2 * C * sizeof(float);      // the apply pass parks c1 / c2 there first
     (void)c1c2_ws;            // the finalize that filled it now lives in the apply pass
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
 #define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
