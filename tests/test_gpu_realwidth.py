@@ -56,6 +56,8 @@ REAL_CONV = [
 
 
 REAL_CONV5 = [          # deployed RepUNet [3,5] -> 5x5 (models/reparm_unet.py:139) at its real widths, whole 16x32 tiles
+    (2, 12, 20, 24, 40),        # ragged: the generic instantiations (bounds checked per lane) of the same entry points
+    (1, 9, 33, 64, 72),
     (2, 32, 64, 64, 64),
     (1, 32, 32, 128, 128),
     (1, 16, 64, 256, 128),
