@@ -85,41 +85,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    // REGISTER PREFETCH: tile t+1's global loads are issued before tile t's MFMAs and stored to LDS after them, so the load
+    // latency hides under a tile of matrix work instead of standing between two of them (fp32 3x3: the staging of a
+    // 32 x 32-channel block was as long as its MFMAs; 175 -> see DESIGN for the step).  8 + 11 uint4 per thread.
+    constexpr int DZ_IT = DZ_UNITS / 256, X_IT = (HALO_UNITS + 255) / 256;
+    static_assert(DZ_UNITS % 256 == 0, "dz tile divides among the threads");
+    uint4 pdz[DZ_IT], px_[X_IT];
+    auto fetch = [&](int tile) {
         int t = tile;
         const int tw_i = t % a.tiles_w; t /= a.tiles_w;
         const int th_i = t % a.tiles_h;
         const int n = t / a.tiles_h;
         const int h0 = th_i * TH, w0 = tw_i * TW;
-
-        __syncthreads();   // previous tile's reads are done
-        // ---- stage dz tile: 256 pixels x 128 bytes ----
         {
             const T* base = dzp + (size_t)n * a.Hout * a.Wout * a.lddz + a.dzoff + co0;
-            for (int u = tid; u < DZ_UNITS; u += 256) {
+#pragma unroll
+            for (int it = 0; it < DZ_IT; ++it) {
+                const int u = tid + it * 256;
                 const int pix = u >> 3, q = u & 7;
                 const int r = pix >> 5, c = pix & 31;
                 const int ho = h0 + r, wo = w0 + c;
                 const bool ok = ho < a.Hout && wo < a.Wout && (co0 + q * EPV) < a.Cout;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) v = *(const uint4*)(base + ((size_t)ho * a.Wout + wo) * a.lddz + q * EPV);
-                *(uint4*)(s_dz + rec128_off(pix, q * 16)) = v;
+                pdz[it] = make_uint4(0, 0, 0, 0);
+                if (ok) pdz[it] = *(const uint4*)(base + ((size_t)ho * a.Wout + wo) * a.lddz + q * EPV);
             }
         }
-        // ---- stage x halo: HH x HWD pixels x 128 bytes ----
         {
             const T* base = xp + (size_t)n * a.Hin * a.Win * a.ldx + a.xoff + ci0;
-            for (int u = tid; u < HALO_UNITS; u += 256) {
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {
+                const int u = tid + it * 256;
                 const int pix = u >> 3, q = u & 7;
                 const int hr = pix / HWD, hc = pix - hr * HWD;
                 const int row = h0 * SH + hr - a.pad_h, col = w0 + hc - a.pad_w;
-                const bool ok = row >= 0 && row < a.Hin && col >= 0 && col < a.Win && (ci0 + q * EPV) < a.Cin;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (ok) v = *(const uint4*)(base + ((size_t)row * a.Win + col) * a.ldx + q * EPV);
-                *(uint4*)(s_x + rec128_off(pix, q * 16)) = v;
+                const bool ok = u < HALO_UNITS && row >= 0 && row < a.Hin && col >= 0 && col < a.Win && (ci0 + q * EPV) < a.Cin;
+                px_[it] = make_uint4(0, 0, 0, 0);
+                if (ok) px_[it] = *(const uint4*)(base + ((size_t)row * a.Win + col) * a.ldx + q * EPV);
             }
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int it = 0; it < DZ_IT; ++it) {
+            const int u = tid + it * 256;
+            *(uint4*)(s_dz + rec128_off(u >> 3, (u & 7) * 16)) = pdz[it];
+        }
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < HALO_UNITS) *(uint4*)(s_x + rec128_off(u >> 3, (u & 7) * 16)) = px_[it];
+        }
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();   // previous tile's reads are done
+        stash();
         __syncthreads();
+        if (tile + 1 < t_end) fetch(tile + 1);
 
         if constexpr (sizeof(T) == 2) {
             // K-step = one tile row (32 pixels)
@@ -143,19 +165,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 }
             }
         } else {
-            // K-step = 4 pixels; A[row=l15][k=g] = dz[pix+g][co], B[k=g][col=l15] = x[pix'+g][ci]
-#pragma unroll 1
-            for (int r = 0; r < TH; ++r) {
-#pragma unroll 1
-                for (int c4 = 0; c4 < TW; c4 += 4) {
-                    const float av = *(const float*)(s_dz + rec128_off(r * 32 + c4 + g, (wco + l15) * 4));
+            // K-step = 4 pixels; A[row=l15][k=g] = dz[pix+g][co], B[k=g][col=l15] = x[pix'+g][ci].  The fragments of step k+1 are
+            // read from LDS before the MFMAs of step k (two register sets), so an LDS round trip is covered by a step of matrix work.
+            constexpr int NK = TH * (TW / 4);
+            auto rd = [&](int ks, float& av, float (&bv)[TG]) {
+                const int r = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
+                av = *(const float*)(s_dz + rec128_off(r * 32 + c4 + g, (wco + l15) * 4));
 #pragma unroll
-                    for (int t2 = 0; t2 < TG; ++t2) {
-                        const int kh = t2 / KW, kw = t2 % KW;
-                        const float bv = *(const float*)(s_x + rec128_off((r * SH + kh) * HWD + kw + c4 + g, (wci + l15) * 4));
-                        acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t2][0][0], 0, 0, 0);
-                    }
+                for (int t2 = 0; t2 < TG; ++t2) {
+                    const int kh = t2 / KW, kw = t2 % KW;
+                    bv[t2] = *(const float*)(s_x + rec128_off((r * SH + kh) * HWD + kw + c4 + g, (wci + l15) * 4));
                 }
+            };
+            float a0, a1, b0[TG], b1[TG];
+            rd(0, a0, b0);
+#pragma unroll 1
+            for (int ks = 0; ks < NK; ks += 2) {
+                rd(ks + 1, a1, b1);
+#pragma unroll
+                for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t2], acc[t2][0][0], 0, 0, 0);
+                if (ks + 2 < NK) rd(ks + 2, a0, b0);
+#pragma unroll
+                for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t2], acc[t2][0][0], 0, 0, 0);
             }
         }
     }
