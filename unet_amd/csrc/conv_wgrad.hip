@@ -28,31 +28,19 @@ __device__ __forceinline__ int rec128_off(int pix, int b) {
     return pix * 128 + (b ^ ((((pix >> 1) & 1) << 6) | (((pix >> 3) & 1) << 5)));
 }
 
+// The x halo image swizzles by the record's COLUMN inside its halo row (not by its linear index): a lane's byte offset for
+// (kernel column kw, K-step column c4) is then the same in every halo row, and the row enters the read as an immediate.
+__device__ __forceinline__ int recx_off(int pix, int col, int b) {
+    return pix * 128 + (b ^ ((((col >> 1) & 1) << 6) | (((col >> 3) & 1) << 5)));
+}
+
 template <typename T> struct WG;
 template <> struct WG<__bf16> { static constexpr int WT = 2; static constexpr int CT = 64; };   // wave tile 2x2 MFMA tiles, block 64x64
 template <> struct WG<float>  { static constexpr int WT = 1; static constexpr int CT = 32; };   // wave tile 1x1, block 32x32
 
-// A/B fragment of a 16(channel) x K(pixel) operand for one K-step.
-//   bf16: K-step = 32 pixels (pix0 .. pix0+31), two transposing reads per lane
-//   f32 : K-step = 4 pixels, one dword per lane per MFMA
-template <typename T> struct Frag;
-template <> struct Frag<__bf16> {
-    uint4 v;
-    // img: LDS image base; pix0: first pixel record of the 32-pixel K-step; chb: byte offset of the
-    // 16-channel tile inside the record (multiple of 32)
-    __device__ __forceinline__ void load(const char* img, int pix0, int chb, int lane) {
-        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-        const int pa = pix0 + 8 * g + q;
-        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rec128_off(pa, chb + 8 * p)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + rec128_off(pa + 4, chb + 8 * p)));
-        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-        v = make_uint4(l2.x, l2.y, h2.x, h2.y);
-    }
-};
-
 template <typename T, int KH, int KW, int SH, int TG>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {      // two workgroups per CU (LDS: 76 KB each): at most 256 registers per lane
+    static_assert(sizeof(T) == 4, "the exact-f32 path; bf16 weight gradients are conv_wgrad2.hip's");
     constexpr int TH = 8, TW = 32;
     constexpr int HH = (TH - 1) * SH + KH, HWD = TW - 1 + KW;
     constexpr int EPV = TT<T>::EPV;
@@ -85,6 +73,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int t_begin = split * a.tiles_per_split;
     const int t_end = min(t_begin + a.tiles_per_split, a.tiles_total);
 
+    // per-lane LDS byte offsets of the fragment reads (f32 path): dz record (c4 + g) of a tile row, x record (kw + c4 + g) of a halo row
+    int aoff[TW / 4], boff[KW][TW / 4];
+#pragma unroll
+    for (int c = 0; c < TW / 4; ++c) {
+        aoff[c] = rec128_off(4 * c + g, (wco + l15) * 4);
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) boff[kw][c] = recx_off(kw + 4 * c + g, kw + 4 * c + g, (wci + l15) * 4);
+    }
     // REGISTER PREFETCH: tile t+1's global loads are issued before tile t's MFMAs and stored to LDS after them, so the load
     // latency hides under a tile of matrix work instead of standing between two of them (fp32 3x3: the staging of a
     // 32 x 32-channel block was as long as its MFMAs; 175 -> see DESIGN for the step).  8 + 11 uint4 per thread.
@@ -133,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < HALO_UNITS) *(uint4*)(s_x + rec128_off(u >> 3, (u & 7) * 16)) = px_[it];
+            if (u < HALO_UNITS) *(uint4*)(s_x + recx_off(u >> 3, (u >> 3) % HWD, (u & 7) * 16)) = px_[it];
         }
     };
     if (t_begin < t_end) fetch(t_begin);
@@ -143,43 +139,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         __syncthreads();
         if (tile + 1 < t_end) fetch(tile + 1);
 
-        if constexpr (sizeof(T) == 2) {
-            // K-step = one tile row (32 pixels)
-#pragma unroll 1
-            for (int r = 0; r < TH; ++r) {
-                Frag<__bf16> fa[WT];
-#pragma unroll
-                for (int i = 0; i < WT; ++i) fa[i].load(s_dz, r * 32, (wco + 16 * i) * 2, lane);
-#pragma unroll
-                for (int t2 = 0; t2 < TG; ++t2) {
-                    const int kh = t2 / KW, kw = t2 % KW;
-                    Frag<__bf16> fb[WT];
-#pragma unroll
-                    for (int j = 0; j < WT; ++j) fb[j].load(s_x, (r * SH + kh) * HWD + kw, (wci + 16 * j) * 2, lane);
-#pragma unroll
-                    for (int i = 0; i < WT; ++i)
-#pragma unroll
-                        for (int j = 0; j < WT; ++j)
-                            acc[t2][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                __builtin_bit_cast(bf16x8, fa[i].v), __builtin_bit_cast(bf16x8, fb[j].v), acc[t2][i][j], 0, 0, 0);
-                }
-            }
-        } else {
-            // K-step = 4 pixels; A[row=l15][k=g] = dz[pix+g][co], B[k=g][col=l15] = x[pix'+g][ci].  The fragments of step k+1 are
-            // read from LDS before the MFMAs of step k (two register sets), so an LDS round trip is covered by a step of matrix work.
+        {
+            // K-step = 4 pixels; A[row=l15][k=g] = dz[pix+g][co], B[k=g][col=l15] = x[pix'+g][ci].  Every LDS address is a
+            // per-lane offset fixed for the kernel's life (aoff / boff, set up once) plus a compile-time immediate (the tile row
+            // and the kernel row): the loop is fully unrolled and spends no vector instruction on addresses -- with them
+            // (5 per MFMA) two waves per SIMD could not keep the matrix pipe fed.  The fragments of step k+1 are read before the
+            // MFMAs of step k.
             constexpr int NK = TH * (TW / 4);
             auto rd = [&](int ks, float& av, float (&bv)[TG]) {
-                const int r = ks / (TW / 4), c4 = (ks % (TW / 4)) * 4;
-                av = *(const float*)(s_dz + rec128_off(r * 32 + c4 + g, (wco + l15) * 4));
+                const int r = ks / (TW / 4), ci4 = ks % (TW / 4);
+                av = *(const float*)(s_dz + aoff[ci4] + r * (32 * 128));
 #pragma unroll
                 for (int t2 = 0; t2 < TG; ++t2) {
                     const int kh = t2 / KW, kw = t2 % KW;
-                    bv[t2] = *(const float*)(s_x + rec128_off((r * SH + kh) * HWD + kw + c4 + g, (wci + l15) * 4));
+                    bv[t2] = *(const float*)(s_x + boff[kw][ci4] + (r * SH + kh) * (HWD * 128));
                 }
             };
             float a0, a1, b0[TG], b1[TG];
             rd(0, a0, b0);
-#pragma unroll 1
+#pragma unroll
             for (int ks = 0; ks < NK; ks += 2) {
                 rd(ks + 1, a1, b1);
 #pragma unroll
