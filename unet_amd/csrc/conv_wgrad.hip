@@ -145,26 +145,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {      
             // and the kernel row): the loop is fully unrolled and spends no vector instruction on addresses -- with them
             // (5 per MFMA) two waves per SIMD could not keep the matrix pipe fed.  The fragments of step k+1 are read before the
             // MFMAs of step k.
-            constexpr int NK = TH * (TW / 4);
-            auto rd = [&](int ks, float& av, float (&bv)[TG]) {
-                const int r = ks / (TW / 4), ci4 = ks % (TW / 4);
-                av = *(const float*)(s_dz + aoff[ci4] + r * (32 * 128));
+            // One tile row (8 K-steps) is unrolled at a time: unrolling all 64 lets the compiler hoist reads until it spills.
+            constexpr int KS = TW / 4;
+#pragma unroll 1
+            for (int r = 0; r < TH; ++r) {
+                const char* dzr = s_dz + r * (32 * 128);
+                const char* xr = s_x + r * SH * (HWD * 128);
+                auto rd = [&](int ci4, float& av, float (&bv)[TG]) {
+                    av = *(const float*)(dzr + aoff[ci4]);
 #pragma unroll
-                for (int t2 = 0; t2 < TG; ++t2) {
-                    const int kh = t2 / KW, kw = t2 % KW;
-                    bv[t2] = *(const float*)(s_x + boff[kw][ci4] + (r * SH + kh) * (HWD * 128));
+                    for (int t2 = 0; t2 < TG; ++t2) {
+                        const int kh = t2 / KW, kw = t2 % KW;
+                        bv[t2] = *(const float*)(xr + boff[kw][ci4] + kh * (HWD * 128));
+                    }
+                };
+                float a0, a1, b0[TG], b1[TG];
+                rd(0, a0, b0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ks += 2) {
+                    rd(ks + 1, a1, b1);
+#pragma unroll
+                    for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t2], acc[t2][0][0], 0, 0, 0);
+                    if (ks + 2 < KS) rd(ks + 2, a0, b0);
+#pragma unroll
+                    for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t2], acc[t2][0][0], 0, 0, 0);
                 }
-            };
-            float a0, a1, b0[TG], b1[TG];
-            rd(0, a0, b0);
-#pragma unroll
-            for (int ks = 0; ks < NK; ks += 2) {
-                rd(ks + 1, a1, b1);
-#pragma unroll
-                for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t2], acc[t2][0][0], 0, 0, 0);
-                if (ks + 2 < NK) rd(ks + 2, a0, b0);
-#pragma unroll
-                for (int t2 = 0; t2 < TG; ++t2) acc[t2][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t2], acc[t2][0][0], 0, 0, 0);
             }
         }
     }
