@@ -2,15 +2,15 @@
 //
 //   dW[tap][co][ci] = sum over output pixels m of  dz[m][co] * x[SH*m + tap][ci]
 //
-// i.e. a GEMM with M = Cout, N = Cin (per tap) and K = N*Hout*Wout pixels.  With NHWC storage the
-// reduction index (pixel) is the strided one, so for bf16 both MFMA operands are fetched from
-// pixel-major LDS images with the gfx950 transposing read ds_read_b64_tr_b16; the f32 path reads
-// one dword per lane for the exact f32 MFMA.
+// i.e. a GEMM with M = Cout, N = Cin (per tap) and K = N*Hout*Wout pixels.  This file is the exact-f32 path (fp32 mode, the
+// parity mode of the shipped `amp: false` configs): one dword per lane and v_mfma_f32_16x16x4_f32; the bf16 weight gradients
+// are conv_wgrad2.hip's.  It also holds the split-K reduce kernels and the C entry point of both.
 //
-// Workgroup (4 waves): a block of 128 bytes of output channels x 128 bytes of input channels
-// (64x64 bf16, 32x32 f32) x all taps of one tap group, accumulated in registers over a contiguous
-// range of 8x32 pixel tiles; the partial block goes to slab[split][tap][co][ci] (plain stores) and
-// a second kernel sums the slabs in a fixed order (bitwise reproducible) into the OIHW gradient.
+// Workgroup (4 waves, two per CU): a block of 32 output channels x 32 input channels x all taps of the launch, accumulated
+// in registers over a contiguous range of 8x32 pixel tiles staged in LDS as 128-byte pixel records; the next tile's global
+// loads sit in registers while the current one is multiplied; the partial block goes to slab[split][tap][co][ci] (plain
+// stores) and a second kernel sums the slabs in a fixed order (bitwise reproducible) into the OIHW gradient.
+//
 //
 // Serves: nn.Conv2d weight grads (reference models/unet.py:10,13; reparm_unet.py:55-61) and the
 // nn.ConvTranspose2d(k=2,s=2) weight grad (models/unet.py:35) through the [N,2H,W,2C] view.
