@@ -328,7 +328,7 @@ extern "C" int unet_conv_wgrad(int dtype, int kh, int kw, int stride_h,
     UNET_CHECK(N > 0 && Hout > 0 && Wout > 0, "empty wgrad problem");
     UNET_CHECK((size_t)Hin * Win * ldx < (1ull << 31) && (size_t)Hout * Wout * lddz < (1ull << 31), "image exceeds 2^31 elements");
     WgradArgs a;
-    a.dz = dz; a.x = x; a.slab = slab;
+    a.dz = dz; a.x = x; a.slab = slab; a.tq = nullptr;
     a.N = N; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.ldx = ldx; a.xoff = xoff;
     a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.lddz = lddz; a.dzoff = dzoff;
     a.pad_h = pad_h; a.pad_w = pad_w;

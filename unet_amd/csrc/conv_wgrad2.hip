@@ -20,6 +20,7 @@
 #include "common.h"
 #include "wgrad_args.h"
 #include "lds_dma.h"
+#include "tile_queue.h"
 
 __device__ __attribute__((aligned(64))) uint4 g_wgrad_zero[4];   // source of every padded 16-byte piece
 
@@ -69,9 +70,15 @@ struct Wg2Cfg {
 // 60-180 cycles of issue (it waits for the memory pipeline to take the one before); spent by a matrix wave, as in the
 // 8-wave form, those cycles are MFMA cycles (the loop without its requests ran 1.5x faster); spent by a wave that has
 // nothing else to do they are free.  Needs the kernel to fit 168 registers (three waves per SIMD).
-template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false>
+// DYN = true (request-wave form only): the pixel tiles come from atomic queues, one per XCD and channel block (tile_queue.h).
+// The workgroups of an XCD that share a channel block draw consecutive tiles of that XCD's range, so the channel blocks of
+// an XCD still walk the same pixels at about the same time (shared through its L2, as in the static order); a dry queue
+// steals from the fullest queue of the same channel block.  Request wave 8 draws the tile after next while the next one's
+// DMA is in flight; the ids travel through four LDS words.
+template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false, bool DYN = false>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs a, int nchan_ci, int nchan, FastDiv d_tw, FastDiv d_th) {
     static_assert(!SPEC || !GEN, "request waves use the fast DMA plan");
+    static_assert(!DYN || SPEC, "tile queues are drawn by a request wave");
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
     constexpr int REC = C::REC, SLOTS = C::SLOTS, RPP = C::RPP, HWD = C::HWD, NT = C::NT, CT = C::CT;
 
@@ -225,12 +232,81 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
 #endif
         if constexpr (GEN) issue_gen(tile, stage_off); else issue_fast(tile, stage_off);
     };
-    if (t_begin < t_end && requester) issue(t_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     int cur = 0;
-    if (SPEC && requester) {
+    int* ring = (int*)(smem + C::SMEM);                 // DYN: ids of tiles k .. k+2 of this workgroup, slot k & 3
+    auto ring_at = [&](int k) { return __builtin_amdgcn_readfirstlane(ring[k & 3]); };
+    if constexpr (DYN) {
+        const int xcd = (int)blockIdx.x & 7;
+        const int span = (((int)gridDim.x >> 3) / nchan) * a.tiles_per_split;          // tiles of one XCD's range
+        auto q_end = [&](int x2) { return min((x2 + 1) * span, a.tiles_total); };
+        auto q_tile = [&](int x2, unsigned m) {
+            const long long t = (long long)x2 * span + m;
+            return t < (long long)q_end(x2) ? (int)t : TQ_INVALID;
+        };
+        int victim = xcd;
+        bool dry = false;
+        auto fetch = [&]() -> int {                     // wave 8, all lanes
+            if (dry) return TQ_INVALID;
+            for (int tries = 0; tries < 4; ++tries) {
+                unsigned m = 0;
+                if (lane == 0) m = atomicAdd(&a.tq[victim * nchan + chan], 1u);
+                m = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+                const int t = q_tile(victim, m);
+                if (t != TQ_INVALID) return t;
+                int rem = 0;                            // that queue is dry: the fullest queue of this channel block
+                if (lane < 8) {
+                    const unsigned nx = __hip_atomic_load(&a.tq[lane * nchan + chan], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rem = q_end(lane) - lane * span - (int)nx;
+                }
+                int best = -1, bestrem = 0;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) {
+                    const int r = __builtin_amdgcn_readlane(rem, l);
+                    if (r > bestrem) { bestrem = r; best = l; }
+                }
+                if (best < 0) break;
+                victim = best;
+            }
+            dry = true;
+            return TQ_INVALID;
+        };
+        if (wave == 8) {
+            const int t0 = fetch();
+            const int t1 = fetch();
+            if (lane == 0) { ring[0] = t0; ring[1] = t1; }
+        }
+        __syncthreads();
+        if (requester && ring_at(0) != TQ_INVALID) issue(ring_at(0), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (requester) {
+            for (int k = 0;; ++k) {
+                if (ring_at(k) == TQ_INVALID) break;
+                const int tn = ring_at(k + 1);
+                if (tn != TQ_INVALID) issue(tn, (cur ^ 1) * C::STAGE);
+                if (wave == 8) {
+                    const int t2 = fetch();             // its round trip runs under the DMA just requested
+                    if (lane == 0) ring[(k + 2) & 3] = t2;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (wave == 8 && lane == 0) {               // the last workgroup to finish hands the slot back zeroed
+                if (atomicAdd(&a.tq[TQ_DONE], 1u) == gridDim.x - 1) {
+                    for (int i = 0; i < 8 * nchan; ++i) a.tq[i] = 0u;
+                    a.tq[TQ_DONE] = 0u;
+                }
+            }
+            return;
+        }
+    } else {
+        if (t_begin < t_end && requester) issue(t_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    if (!DYN && SPEC && requester) {
         // request wave: tile t+1 goes out as soon as the barrier has freed its stage; the barrier that ends tile t
         // says both "t+1 has landed" (these waves wait before they arrive) and "nobody reads stage cur any more"
         for (int tile = t_begin; tile < t_end; ++tile) {
@@ -243,7 +319,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
         }
         return;
     }
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    int kdyn = 0;
+    bool go = DYN ? ring_at(0) != TQ_INVALID : t_begin < t_end;
+    for (int tile = t_begin; go; ++tile) {
         const bool more = tile + 1 < t_end;
         const char* img = smem + cur * C::STAGE;
         auto load_a = [&](int r, uint4* fa) {
@@ -325,6 +403,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
         if (!SPEC) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed (this wave's pieces)
         __syncthreads();                                    // ... everyone's; and everyone is done reading `cur`
         cur ^= 1;
+        go = DYN ? ring_at(++kdyn) != TQ_INVALID : tile + 1 < t_end;
     }
 
     // ---- store the partial block: D[row = co = 4g+reg][col = ci = l15] ----
@@ -344,18 +423,30 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv_wgrad2_kernel(WgradArgs
             }
 }
 
-template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false>
+template <int KH, int KW, int SH, int WT, int TH, bool GEN, bool SPEC = false, bool DYN = false>
 static int launch_wgrad2g(WgradArgs a, hipStream_t stream, int nsplit) {
     using C = Wg2Cfg<KH, KW, SH, WT, TH>;
+    constexpr int LDS = C::SMEM + (DYN ? 64 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC, DYN>, LDS)) return rc;
     a.tiles_h = (a.Hout + TH - 1) / TH; a.tiles_w = (a.Wout + 31) / 32;
     a.tiles_total = a.N * a.tiles_h * a.tiles_w;
     a.tiles_per_split = (a.tiles_total + nsplit - 1) / nsplit;
     const int nco = (a.Cout + C::CT - 1) / C::CT, nci = (a.Cin + C::CT - 1) / C::CT;
     UNET_CHECK((unsigned long long)a.tiles_total * (unsigned)(a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC>), dim3((unsigned)(nsplit * nco * nci)), dim3(SPEC ? 768 : 512), C::SMEM, stream,
+    if constexpr (!DYN && SPEC && C::SMEM + 64 <= 160 * 1024) {       // (the widest halos leave no LDS for the queue's four words)
+        // tile queues (tile_queue.h): a whole number of workgroups per XCD and channel block, at most 16 channel blocks, and
+        // enough tiles per workgroup for the choice to matter
+        const int nchan = nco * nci, grid = nsplit * nchan;
+        if (tileq_enabled() && nchan <= 16 && grid % (8 * nchan) == 0 && a.tiles_per_split >= 4) {
+            a.tq = tileq_next_slot();
+            if (a.tq == nullptr) return -3;
+            return launch_wgrad2g<KH, KW, SH, WT, TH, GEN, SPEC, true>(a, stream, nsplit);
+        }
+    }
+    hipLaunchKernelGGL((conv_wgrad2_kernel<KH, KW, SH, WT, TH, GEN, SPEC, DYN>), dim3((unsigned)(nsplit * nco * nci)), dim3(SPEC ? 768 : 512), LDS, stream,
                        a, nci, nco * nci, make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;

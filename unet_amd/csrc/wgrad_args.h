@@ -8,4 +8,5 @@ struct WgradArgs {
     int Hout, Wout, Cout, lddz, dzoff;
     int pad_h, pad_w, tiles_h, tiles_w;
     int tiles_total, tiles_per_split;
+    unsigned* tq;     // dynamic tile queue slot (tile_queue.h), or NULL: static split of the tiles
 };
