@@ -309,6 +309,16 @@ int unet_comm_destroy(void* comm);
 int unet_allreduce_bucket(void* comm, void* buf, long long count, int dtype, void* stream);
 int unet_broadcast(void* comm, void* buf, long long count, int dtype, int root, void* stream);
 
+/* Tile scheduling of the persistent bf16 conv / weight-gradient kernels.  No counterpart in the reference (DDP there shares
+ * the GPU between cuDNN's kernels and NCCL's through the hardware scheduler).  These kernels own every CU and by default
+ * split their tiles statically, so a collective's workgroups that hold a few CUs while one is launched delay it by their
+ * whole hold time.  level 1: launches with at least three rounds of tiles draw them from per-XCD atomic
+ * queues instead (a late CU takes fewer tiles; a dry queue steals); which workgroup computes which tile is then timing
+ * dependent, so split-K partial sums are grouped differently from run to run (last-bit differences in dW, none in
+ * activations).  level 2: also launches with few tiles per workgroup (tests).  0: static (default; also the environment
+ * variable UNET_AMD_DYNAMIC_TILES).  Process-wide; takes effect at the next launch. */
+int unet_set_dynamic_tiles(int level);
+
 #ifdef __cplusplus
 }
 #endif

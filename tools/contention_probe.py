@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--sweep", default="0:0,16:250,32:250,32:1000,64:250,64:1000,32:4000,0:0")
+    ap.add_argument("--side-index", type=int, default=0, help="use the (k+1)-th stream created (HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues round robin; two streams on one queue serialise)")
+    ap.add_argument("--side-priority", type=int, default=-1, help="-1: high-priority side stream, which gets a hardware queue of its own; 0: a pool stream, which on this image lands on the compute stream's hardware queue, so the two serialise")
     args = ap.parse_args()
 
     lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcu_thief.so"))
@@ -70,7 +72,8 @@ def main():
     x = torch.rand(args.batch, 1, args.size, args.size, generator=g).to(dev)
     y = (torch.rand(args.batch, args.size, args.size, generator=g) > 0.95).long().to(dev)
 
-    side = torch.cuda.Stream()
+    _spare = [torch.cuda.Stream(priority=args.side_priority) for _ in range(args.side_index)]
+    side = torch.cuda.Stream(priority=args.side_priority)
     sink = torch.zeros(4, dtype=torch.int32, device=dev)
     cfg = {"wgs": 0, "us": 0}
     real_all_reduce = dist.all_reduce

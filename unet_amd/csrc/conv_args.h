@@ -13,4 +13,5 @@ struct ConvArgs {
     void* y2;
     int ldy2, yoff2, csplit;
     int flags;      // bit 0: y += conv (accumulate into the existing output), bit 1: ReLU on the result
+    unsigned* tq;   // dynamic tile queue slot (tile_queue.h) or NULL; set by the launcher
 };

@@ -18,6 +18,8 @@
 #include "common.h"
 #include "conv_args.h"
 #include "lds_dma.h"
+#include "tile_queue.h"
+#include <climits>
 #include <type_traits>
 #include <cstdlib>
 
@@ -83,11 +85,18 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // kernel per phase; a 1 x k kernel is k columns of one row each, its A fragments double-buffered per column.
 // ACC = true (specialised kernel, no request waves): flags bit 0 ADDS the result to what the destination holds -- the branch
 // dgrads of a RepUNet block (models/reparm_unet.py:62-72,110-122: six convolutions of one input) summed into one dx.
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false>
+// DYN = true (128-channel tiles and the request-wave kernel): tiles are drawn from one atomic queue per XCD (tile_queue.h): the
+// workgroups of an XCD take consecutive tiles of that XCD's eighth of the tile range, a dry queue steals from the fullest.
+// A workgroup holds the ids of its current and its next tile (the DMA cursors run up to one tile ahead; with Cin >= 64 a
+// tile has at least two chunks, so no cursor reaches tile k+2 before the last chunk of tile k): two are drawn at the start,
+// then matrix wave 7 (it issues no DMA, so its memory counter is free) requests the id of tile k+2 at the top of tile k and
+// collects it at the tile's last phase; the ids travel through four LDS words to the cursors and the request waves.
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC, KH, KW>;
     static_assert((KH == 3 && KW == 3) || (!GEN && !DST && !SPEC), "other than 3x3: the specialised kernel only");
     static_assert(!ACC || (!GEN && !DST && !SPEC), "accumulating epilogue: the specialised kernel without request waves");
+    static_assert(!DYN || (!GEN && !DST && !ACC && KH == 3 && KW == 3 && (WC == 2 || SPEC)), "tile queues: 128-channel tiles or request waves");
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -264,21 +273,86 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     };
 
     // ---- issue-side cursors: the next weight phase and the next halo chunk to request ------------------
-    struct Cursor { int tile_i, c, ph, seq; Tile t; bool valid; };
+    int* ring = (int*)(smem + C::SMEM);                 // DYN: ids of this workgroup's tiles k-1 .. k+2, slot k & 3
+    auto ring_at = [&](int k) { return __builtin_amdgcn_readfirstlane(ring[k & 3]); };
+    struct Cursor { int tile_i, c, ph, seq, sn; Tile t; bool valid; };
     auto cursor_at = [&](int tile_i) {
         Cursor q;
-        q.tile_i = tile_i; q.c = 0; q.ph = 0; q.seq = 0;
+        q.tile_i = tile_i; q.c = 0; q.ph = 0; q.seq = 0; q.sn = 0;
         q.valid = tile_i < total_tiles;
         q.t = decode(q.valid ? tile_i : 0);
         return q;
     };
     auto next_tile = [&](Cursor& q) {
-        q.c = 0; q.tile_i += gridDim.x; q.seq ^= 1;
+        q.c = 0; q.seq ^= 1;
+        if constexpr (DYN) q.tile_i = ring_at(++q.sn); else q.tile_i += gridDim.x;
         q.valid = q.tile_i < total_tiles;
         if (q.valid) q.t = decode(q.tile_i);
     };
     if ((int)blockIdx.x >= total_tiles) return;
-    const int lblock = xcd_block_id();
+    // ---- DYN: the tile queue of this workgroup's XCD (wave 7 draws) ----------------------------------------------
+    const int tq_span = (total_tiles + 7) >> 3;          // tiles of one XCD's range
+    auto q_end = [&](int x2) { return min((x2 + 1) * tq_span, total_tiles); };
+    auto q_tile = [&](int x2, unsigned m) {
+        const long long t = (long long)x2 * tq_span + m;
+        return t < (long long)q_end(x2) ? (int)t : TQ_INVALID;
+    };
+    int tq_victim = (int)blockIdx.x & 7, tq_pend_q = 0;
+    bool tq_dry = false, tq_has_pend = false;
+    unsigned tq_pend = 0;
+    auto tq_request = [&]() {                            // wave 7: the atomic goes out, nobody waits
+        tq_has_pend = !tq_dry;
+        tq_pend_q = tq_victim;
+        if (tq_has_pend && lane == 0) tq_pend = atomicAdd(&a.tq[tq_victim], 1u);
+    };
+    auto tq_collect = [&]() -> int {                     // wave 7: the requested id; a dry queue steals (synchronously, rare)
+        if (!tq_has_pend) return TQ_INVALID;
+        tq_has_pend = false;
+        int t = q_tile(tq_pend_q, (unsigned)__builtin_amdgcn_readfirstlane((int)tq_pend));
+        for (int tries = 0; t == TQ_INVALID && tries < 4; ++tries) {
+            int rem = 0;
+            if (lane < 8) {
+                const unsigned nx = __hip_atomic_load(&a.tq[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rem = q_end(lane) - lane * tq_span - (int)nx;
+            }
+            int best = -1, bestrem = 0;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                const int r = __builtin_amdgcn_readlane(rem, l);
+                if (r > bestrem) { bestrem = r; best = l; }
+            }
+            if (best < 0) break;
+            tq_victim = best;
+            unsigned m2 = 0;
+            if (lane == 0) m2 = atomicAdd(&a.tq[best], 1u);
+            t = q_tile(best, (unsigned)__builtin_amdgcn_readfirstlane((int)m2));
+        }
+        if (t == TQ_INVALID) tq_dry = true;
+        return t;
+    };
+    auto tq_done = [&]() {                               // wave 7: the last workgroup to finish hands the slot back zeroed
+        if (lane == 0 && atomicAdd(&a.tq[TQ_DONE], 1u) == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.tq[i] = 0u;
+            a.tq[TQ_DONE] = 0u;
+        }
+    };
+    if constexpr (DYN) {
+        if (wave == 7) {                                 // the first two tiles in one draw from the own queue
+            unsigned m = 0;
+            if (lane == 0) m = atomicAdd(&a.tq[tq_victim], 2u);
+            m = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+            const int t0 = q_tile(tq_victim, m), t1 = q_tile(tq_victim, m + 1);
+            if (t1 == TQ_INVALID) tq_dry = true;         // an id after an invalid one would never be computed: stop drawing
+            if (lane == 0) { ring[0] = t0; ring[1] = t1; ring[2] = TQ_INVALID; ring[3] = TQ_INVALID; }
+        }
+        __syncthreads();
+        if (ring_at(0) == TQ_INVALID) {
+            if (wave == 7) tq_done();
+            return;
+        }
+    }
+    const int lblock = DYN ? ring_at(0) : xcd_block_id();
     Cursor wq_ = cursor_at(lblock);        // weights: advances phase by phase
     Cursor hq_ = wq_;                          // halo: advances chunk by chunk
     unsigned hmask = halo_mask(hq_.t);
@@ -346,7 +420,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
             // waves transpose their output through the halo stage just read, so that stage's refill waits for the
             // barrier behind the epilogue (the statistics' first barrier, or one of its own).
             int ws_r = 0, hs_r = 0;
-            for (int t_i = lblock; t_i < total_tiles; t_i += (int)gridDim.x) {
+            for (int t_i = lblock, t_sn = 0; t_i < total_tiles; t_i = DYN ? ring_at(++t_sn) : t_i + (int)gridDim.x) {
                 for (int c = 0; c < nchunks; ++c) {
                     const int need = max(ws_r ? w_mark0 : w_mark1, hs_r ? h_mark0 : h_mark1);
                     wait_landed(need);
@@ -363,7 +437,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
         }
     }
 
-    int tile_i = lblock, tseq = 0;
+    int tile_i = lblock, tseq = 0, tile_sn = 0;
     Tile cur = decode(tile_i);
     int hs = 0, ws = 0;        // stages holding the current chunk's halo / the current phase's weights
     // STAGGER (symmetric scheme, 64-channel tiles): waves 0-3 refill right after the barrier, their SIMD partners
@@ -386,6 +460,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
         for (int r = 0; r < 4; ++r) { run1[i][r] = 0.f; run2[i][r] = 0.f; }
     for (;;) {
         const bool last_tile = tile_i + (int)gridDim.x >= total_tiles;
+        if constexpr (DYN) { if (wave == 7) tq_request(); }        // id of tile k+2, collected at this tile's last phase
         f32x4 acc[4][NPG];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -396,6 +471,12 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #pragma unroll
             for (int ph = 0; ph < NPH; ++ph) {
                 STAMP(1);
+                if constexpr (DYN) {
+                    if (wave == 7 && c == nchunks - 1 && ph == NPH - 1) {
+                        const int t3 = tq_collect();
+                        if (lane == 0) ring[(tile_sn + 2) & 3] = t3;
+                    }
+                }
                 // ---- this phase: TPP taps -----------------------------------------------------------
                 const char* hb = smem + hs * C::H_BYTES;
                 const char* wb = smem + ws * C::W_BYTES;
@@ -703,20 +784,24 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
             __syncthreads();            // the request waves may refill the halo stage the epilogue borrowed
         }
         STAMP(6);
-        tile_i += gridDim.x; tseq ^= 1;
+        tseq ^= 1;
+        if constexpr (DYN) tile_i = ring_at(++tile_sn); else tile_i += gridDim.x;
         if (tile_i >= total_tiles) break;
         cur = decode(tile_i);
     }
+    if constexpr (DYN) { if (wave == 7) tq_done(); }
 #ifdef CV2_TRACE
     if (trc && wave == 0) { g_cv2_trace[2050] = __builtin_amdgcn_s_memtime(); g_cv2_trace[2051] = __builtin_amdgcn_s_memrealtime(); }
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC, KH, KW>;
+    constexpr int LDS = C::SMEM + (DYN ? 64 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static DynLdsOnce lds_once;
-    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC>, C::SMEM)) return rc;
+    if (int rc = ensure_dyn_lds(lds_once, (const void*)conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC, DYN>, LDS)) return rc;
     a.tiles_h = (a.Hout + C::TH - 1) / C::TH; a.tiles_w = (a.Wout + C::TW - 1) / C::TW;
     // STREAMING STORES for outputs far larger than the L2s (8 x 4 MiB): the store burst of one round of tiles (32 workgroups
     // x 128 KiB per XCD) otherwise evicts the weights and halos the next round wants.  Same box: 256->256 @128^2 (268 MB
@@ -727,7 +812,15 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), C::SMEM, stream, a, nco, total,
+    if constexpr (!DYN && !GEN && !DST && !ACC && KH == 3 && KW == 3 && (WC == 2 || SPEC)) {
+        // tile queues (tile_queue.h) for launches with at least three rounds of tiles (two are drawn up front)
+        if (grid == 256 && a.Cin >= 64 && total >= (tileq_level() == 2 ? 256 : tileq_level() == 1 ? 3 * 256 : INT_MAX)) {
+            a.tq = tileq_next_slot();
+            if (a.tq == nullptr) return -3;
+            return launch_conv2<WC, GEN, DST, SPEC, KH, KW, ACC, true>(a, stream);
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC, DYN>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), LDS, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;

@@ -328,7 +328,7 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.ldy = ldy; a.yoff = yoff;
     a.pad_h = pad_h; a.pad_w = pad_w;
     a.tiles_h = (Hout + 7) / 8; a.tiles_w = (Wout + 31) / 32;
-    a.y2 = y2; a.ldy2 = ldy2; a.yoff2 = yoff2; a.csplit = csplit; a.flags = flags;
+    a.y2 = y2; a.ldy2 = ldy2; a.yoff2 = yoff2; a.csplit = csplit; a.flags = flags; a.tq = nullptr;
     hipStream_t s = (hipStream_t)stream;
     if (use_conv2(dtype, kh, kw, stride_h, epi)) {
         UNET_CHECK((size_t)9 * Cout * Cin * 2 < (1ull << 31), "packed weights exceed 2^31 bytes");

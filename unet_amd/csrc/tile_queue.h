@@ -21,4 +21,5 @@ constexpr int TQ_NSLOTS = 1024;
 constexpr int TQ_INVALID = 0x7fffffff;
 
 bool tileq_enabled();                       // UNET_AMD_DYNAMIC_TILES / unet_set_dynamic_tiles
+int tileq_level();                          // 0 off, 1 on for launches with several rounds of tiles, 2 on wherever the kernels allow
 unsigned* tileq_next_slot();                // device pointer to a zeroed slot on the current device (nullptr on failure)

@@ -7,21 +7,24 @@
 static __device__ __align__(256) unsigned g_tileq[TQ_NSLOTS * TQ_SLOT_WORDS];      // zero-initialised; slots clean themselves
 
 static std::atomic<int> g_dyn{-1};
-bool tileq_enabled() {
+int tileq_level() {
     int v = g_dyn.load(std::memory_order_relaxed);
     if (v < 0) {
         const char* e = getenv("UNET_AMD_DYNAMIC_TILES");
-        v = (e && atoi(e) != 0) ? 1 : 0;
+        v = e ? atoi(e) : 0;
+        v = v < 0 ? 0 : v > 2 ? 2 : v;
         g_dyn.store(v, std::memory_order_relaxed);
     }
-    return v != 0;
+    return v;
 }
+bool tileq_enabled() { return tileq_level() > 0; }
 
 // 1: persistent conv / weight-gradient kernels draw their tiles from atomic queues (for runs that share the GPU with
-// collectives: unet_amd.parallel.DataParallel does not switch it on by itself); 0: static partition (default).
+// collectives: unet_amd.parallel.DataParallel does not switch it on by itself); 0: static partition (default);
+// 2: as 1 and also for launches with few tiles per workgroup (the tests use it to reach the stealing path at small sizes).
 // No counterpart in the reference (it has no kernels of its own).
 extern "C" int unet_set_dynamic_tiles(int on) {
-    g_dyn.store(on ? 1 : 0, std::memory_order_relaxed);
+    g_dyn.store(on < 0 ? 0 : on > 2 ? 2 : on, std::memory_order_relaxed);
     return 0;
 }
 

@@ -35,6 +35,13 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+def set_dynamic_tiles(level: int) -> None:
+    """Tile scheduling of the persistent bf16 conv / weight-gradient kernels (include/unet_hip.h: unet_set_dynamic_tiles):
+    0 static partition (default), 1 per-XCD atomic tile queues for launches with several rounds of tiles (runs that share
+    the GPU with collectives), 2 queues wherever the kernels allow (tests)."""
+    check(lib().unet_set_dynamic_tiles(int(level)))
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
