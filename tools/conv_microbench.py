@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
+    ap.add_argument("--per-tile-stats", action="store_true", help="forward with one statistics row per tile (flags bit 2): the request-wave kernel on 64-channel tiles")
     a = ap.parse_args()
     dt = ops.BF16 if a.dtype == "bf16" else ops.F32
     dev = torch.device("cuda:0")
@@ -55,7 +56,7 @@ def main():
         wf, wd = ops.pack_weights(w, 0, dt), ops.pack_weights(w, 1, dt)
         bias = torch.zeros(cout, device=dev)
         flops = 2.0 * N * h * h * cin * cout * 9
-        t_f = timeit(lambda: ops.conv_fwd(x, wf, bias, y, 3, 3, cin, cout, stats=True), a.iters)
+        t_f = timeit(lambda: ops.conv_fwd(x, wf, bias, y, 3, 3, cin, cout, stats=True, per_image_stats=a.per_tile_stats), a.iters)
         t_d = timeit(lambda: ops.conv_fwd(dz, wd, None, dx, 3, 3, cout, cin), a.iters)
         t_w = timeit(lambda: ops.conv_wgrad(dz, x, 3, 3, ws), a.iters)
         rec = dict(layer=name, cin=cin, cout=cout, hw=h, gflop=flops / 1e9,
