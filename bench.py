@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: UNet train step (step_batch: zero_grad -> fwd -> Dice+CE -> bwd -> clip -> AdamW)
 on synthetic 512x512 CT slices, bf16 compute, per-GPU batch 32 (BASELINE.json configs[1]); with
---gpus N > 1 the same per-rank batch under bucketed RCCL gradient all-reduce (weak scaling).
+--gpus N > 1 BASELINE.json configs[3]: global batch 256 under bucketed RCCL gradient all-reduce, i.e. 128 / 64 / 32
+images per rank at N = 2 / 4 / 8 (--batch overrides the per-rank batch).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -146,7 +147,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch; default 32 on one GPU (configs[1]), 256 // N on N > 1 GPUs (configs[3]: global batch 256)")
+    ap.add_argument("--global-batch", type=int, default=256, help="global batch the N > 1 default per-rank batch is derived from")
+    ap.add_argument("--no-single-gpu-ref", action="store_true",
+                    help="N > 1: skip the un-wrapped reference steps each rank times before the data-parallel run")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,6 +165,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     use_dist = world > 1 or args.force_dist
+    if args.batch <= 0:
+        args.batch = 32 if world == 1 else max(1, args.global_batch // world)
+    if use_dist:
+        # HIP's default of 4 hardware queues per process lets torch's RCCL stream land on the compute stream's queue, where
+        # the all-reduces run in order with the kernels instead of under them; must be set before the
+        # first HIP call of the process
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.force_dist:
         os.environ["UNET_AMD_DP_FORCE_COLLECTIVES"] = "1"      # the one-rank rehearsal still launches the RCCL collectives
     if use_dist:
@@ -176,26 +188,54 @@ def main():
     from unet_amd.parallel import DataParallel
     from unet_amd.utils.train_step import step_batch
 
+    from unet_amd.utils.builders import get_optim          # the reference's builder API (utils/builders.py:128-146)
     torch.manual_seed(42)
     model = REGISTRY["unet"](in_channels=1, n_classes=2, features=[64, 128, 256, 512]).to(dev).train()
-    if use_dist:
-        model = DataParallel(model, device_ids=[local_rank])
-    from unet_amd.utils.builders import get_optim          # the reference's builder API (utils/builders.py:128-146)
-    opt = get_optim("adamw", [p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
-    trainer = types.SimpleNamespace(
-        optimizer=opt, amp=(args.dtype == "bf16"), model=model, grad_clip=1.0, cbs=[], current_epoch=1,
-        logger=logging.getLogger("bench"),
-        loss_fn=get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255))
+    engine = model._engine
     scaler = torch.amp.GradScaler(enabled=False)
 
-    g = torch.Generator().manual_seed(42 + rank)
-    x = torch.rand(args.batch, 1, args.size, args.size, generator=g).to(dev)
-    y = (torch.rand(args.batch, args.size, args.size, generator=g) > 0.95).long().to(dev)
+    def make_trainer(m):
+        opt = get_optim("adamw", [p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
+        return types.SimpleNamespace(
+            optimizer=opt, amp=(args.dtype == "bf16"), model=m, grad_clip=1.0, cbs=[], current_epoch=1,
+            logger=logging.getLogger("bench"),
+            loss_fn=get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255))
+
+    def batch_of(n):
+        g = torch.Generator().manual_seed(42 + rank)
+        return (torch.rand(n, 1, args.size, args.size, generator=g).to(dev),
+                (torch.rand(n, args.size, args.size, generator=g) > 0.95).long().to(dev))
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1: what ONE GPU does without the wrapper, measured here on every rank at once (no collective in flight), at this
+    # run's per-rank batch and at the 1-GPU configuration's batch of 32: the two denominators of SURVEY 8(d) C4's efficiency
+    # definitions.  Reported next to `value`; the driver computes its own from the per-N lines.
+    single_ref = {}
+    if world > 1 and not args.no_single_gpu_ref:
+        for nb in sorted({args.batch, 32}):
+            tr = make_trainer(model)
+            xb, yb = batch_of(nb)
+            for i in range(2):
+                step_batch(tr, xb, yb, scaler, batch_idx=i + 1)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(3):
+                step_batch(tr, xb, yb, scaler, batch_idx=i + 1)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            single_ref[nb] = 3 * nb / float(t)              # images/s of the slowest rank running alone
+            del tr, xb, yb
+        torch.cuda.empty_cache()
+
+    if use_dist:
+        model = DataParallel(model, device_ids=[local_rank])
+    trainer = make_trainer(model)
+    x, y = batch_of(args.batch)
 
     for i in range(args.warmup):
         step_batch(trainer, x, y, scaler, batch_idx=i + 1)
@@ -208,6 +248,9 @@ def main():
     last = None
     for i in range(args.steps):
         if i == args.steps - 1 and not args.no_conv_timer:
+            # the instrumented step runs the weight gradients on the compute stream again (product default: a side stream),
+            # so that a launch's event pair brackets that kernel alone and not the time it queued behind the other stream
+            engine.overlap_wgrad = False
             timer.install()
         last = step_batch(trainer, x, y, scaler, batch_idx=i + 1)
     sync()
@@ -228,9 +271,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"UNet features [64,128,256,512] full step_batch (fwd+Dice/CE+bwd+clip+AdamW), "
                                    f"{args.batch}x1x{args.size}x{args.size} per GPU",
-                       "global_batch": args.batch * world, "image_size": args.size,
+                       "global_batch": args.batch * world, "per_rank_batch": args.batch, "image_size": args.size,
                        "parallelism": f"dp{world}", "final_loss": last[2]["main_loss"]},
         }
+        if use_dist:
+            out["config"]["rccl_world_size"] = dist.get_world_size()
+            out["config"]["GPU_MAX_HW_QUEUES"] = os.environ.get("GPU_MAX_HW_QUEUES")
+        if world > 1:
+            # per-rank work is 256/N images: fixed total work from N = 2 on ("strong"); against the N = 1 line (32 images)
+            # it is neither, hence the two measured denominators below
+            out["scaling"] = "strong"
+        if single_ref:
+            out["single_gpu_ref"] = {
+                "images_per_s_same_per_rank_batch": single_ref[args.batch], "images_per_s_batch32": single_ref[32],
+                "efficiency_same_per_rank_batch": value / (world * single_ref[args.batch]),
+                "efficiency_vs_1gpu_batch32": value / (world * single_ref[32]),
+                "note": "un-wrapped step_batch timed on every rank at once before the wrap (3 steps after 2 warm-up, slowest rank)"}
         if not args.no_conv_timer and timer.records:
             fl, ms, n = timer.summary()
             ach = fl / (ms * 1e-3) / 1e12

@@ -30,6 +30,20 @@ def test_wrapper_over_rccl_equals_unwrapped_bit_for_bit(dev):
     assert r.returncode == 0 and "DP SELFCHECK OK" in r.stdout, r.stdout[-3000:]
 
 
+def test_two_ranks_one_gpu_rehearsal(dev):
+    """World size 2 with the real kernels (the 8-GPU run is the driver's): two ranks share this GPU, launched the way the
+    driver launches bench.py (torchrun child processes; the launcher itself never touches the GPU), process group on gloo
+    with the collectives staged through host copies (RCCL refuses two ranks on one device).  tools/dist_rehearsal.py checks
+    rank-0 broadcast at wrap, p.grad == average of the per-rank gradients, several arrival-order buckets, parameters
+    identical on both ranks after full step_batch calls, and that an illegal label on one rank vetoes the update on both."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "tools", "dist_rehearsal.py")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=280)
+    print(r.stdout[-4000:])
+    assert r.returncode == 0 and "DIST REHEARSAL OK (world 2)" in r.stdout, r.stdout[-4000:]
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_world_factor_folded_into_clip_coefficient(dev, world):
     """p.grad holds the all-reduced SUM; clip_and_step(grad_scale=1/world) must act like averaging first and then

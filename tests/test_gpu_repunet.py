@@ -93,9 +93,9 @@ def test_fold_bit_exact_and_deploy(dev, name, ks, mode):
     if mode == "golden_host":
         m.switch_to_deploy(sqrt=_capture_host_sqrt())
     elif mode == "reference":
-        m.switch_to_deploy()                                        # the default
+        assert m.switch_to_deploy(sqrt="reference") is m            # a reference model folded on the CPU
     else:
-        m.switch_to_deploy(sqrt="ieee")
+        assert m.switch_to_deploy() is m                            # the default: "ieee", a reference model folded on the GPU
     post = split(g, "post/")
     sd = m.state_dict()
     assert list(sd) == list(post)                                   # ...reparam_conv.{0,2}.mergedConv.{weight,bias}
@@ -109,7 +109,7 @@ def test_fold_bit_exact_and_deploy(dev, name, ks, mode):
         for k in post:
             assert torch.equal(sd[k].cpu(), post[k]), k
     elif mode == "reference":
-        # default mode: sqrt by torch on THIS host, i.e. what the reference's own switch_to_deploy() computes here:
+        # sqrt by torch's CPU backend on THIS host, i.e. what the reference's own switch_to_deploy() computes here on the CPU:
         # bit-exact against the restated oracle with the live torch sqrt (pinned to the golden by
         # tests/test_oracle_golden.py on the capture host); equal to the golden too wherever this host's sqrt agrees
         live = fold_ref.fold_state(pre_np, ks, sqrt=fold_ref.torch_sqrt)

@@ -57,6 +57,36 @@ def _worker(rank, world, port, q):
             parts = [torch.zeros_like(local[n]) for _ in range(world)]
             dist.all_gather(parts, local[n])
             ok = ok and torch.allclose(p.grad, sum(parts) / world, atol=1e-6)
+        # --- in-place buckets: a second backward while p.grad still holds the first one's bucket views must raise
+        #     (it would overwrite the first micro-step's gradients, not accumulate); zero_grad(set_to_none=True) clears it
+        try:
+            net._grad_hook(["0.weight"], [local["0.weight"]])
+            ok = False
+        except RuntimeError as e:
+            ok = ok and "second backward" in str(e)
+        net.zero_grad(set_to_none=True)
+        # --- a backward that was never finished (exception between backward and finish_grad_sync) is dropped by the next
+        #     one instead of piling up: same buckets, same cached flat buffers
+        nflats = len(dp.reducer._flat_cache)
+        for attempt in range(2):
+            for n in reversed(list(local)):
+                net._grad_hook([n], [local[n] * (attempt + 1)])
+            net._grad_flush()
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        dp.finish_grad_sync()
+        ok = ok and len(dp.reducer._flat_cache) == nflats
+        for n, p in net.named_parameters():
+            parts = [torch.zeros_like(local[n]) for _ in range(world)]
+            dist.all_gather(parts, local[n])
+            ok = ok and torch.allclose(p.grad, 2 * sum(parts) / world, atol=1e-6)
+        net.zero_grad(set_to_none=True)
+        # --- the status word (step_batch: the loss kernel's illegal-label counter) becomes the MAX over ranks, so every
+        #     rank vetoes the same update
+        st = torch.tensor([0.5 + rank, 0.0, 0.0, 3.0 if rank == world - 1 else 0.0])
+        dp.share_status(st[3:4])
+        dp.finish_grad_sync()
+        ok = ok and float(st[3]) == 3.0 and float(st[0]) == 0.5 + rank
         # --- BN buffers: per-rank statistics after a training forward; rank 0's again at the next forward's sync,
         #     broadcast in place through the flat tensors the buffers are views of
         def flat_bufs():

@@ -9,7 +9,11 @@ Launched the way the driver launches bench.py (the launcher never touches the GP
   * after forward + loss + backward + finish_grad_sync every p.grad equals the average of the per-rank gradients
     computed WITHOUT the wrapper from the same weights and the same per-rank inputs;
   * the arrival-order buckets were actually used (more than one all-reduce);
-  * after three full step_batch calls the parameters are still identical on every rank and the loss is finite.
+  * after three full step_batch calls the parameters are still identical on every rank and the loss is finite;
+  * a batch with an illegal label on ONE rank (the reference raises inside loss_fn on that rank, before backward,
+    /root/reference/losses/segmentation.py:8): every rank raises, no rank's parameters, moments or Adam step count move,
+    and the next good step leaves the ranks identical again.
+Collected by pytest as tests/test_gpu_parallel.py::test_two_ranks_one_gpu_rehearsal.
 """
 import copy
 import logging
@@ -129,7 +133,27 @@ def main():
             last = step_batch(trainer, x, y, scaler, batch_idx=i + 1)
         same3 = same_everywhere(list(net.parameters()), world)
         loss = float(last[2]["main_loss"])
-        good = same0 and grads_same and same3 and nb > 1 and worst < tol and loss == loss
+        # illegal label on the last rank only
+        snap = [p.detach().clone() for p in net.parameters()]
+        steps_before = [float(opt.state[p]["step"]) for p in opt.param_groups[0]["params"]]
+        ybad = y.clone()
+        if rank == world - 1:
+            ybad[0, 3, 5] = 2
+        raised = False
+        try:
+            step_batch(trainer, x, ybad, scaler, batch_idx=9)
+        except RuntimeError as e:
+            raised = "Class values must be smaller than num_classes" in str(e)
+        torch.cuda.synchronize()
+        untouched = all(torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
+        steps_same = steps_before == [float(opt.state[p]["step"]) for p in opt.param_groups[0]["params"]]
+        step_batch(trainer, x, y, scaler, batch_idx=10)
+        same_after = same_everywhere(list(net.parameters()), world)
+        moved = not all(torch.equal(a, b.detach()) for a, b in zip(snap, net.parameters()))
+        veto_ok = raised and untouched and steps_same and same_after and moved
+        say(rank, f"{dtype}: illegal label on rank {world - 1}: raised here={raised} parameters untouched={untouched} "
+                  f"Adam step counts unchanged={steps_same}; next step: ranks identical={same_after}")
+        good = same0 and grads_same and same3 and nb > 1 and worst < tol and loss == loss and veto_ok
         ok = ok and good
         if rank == 0:
             print(f"{dtype}: params identical after wrap={same0} buckets={nb} worst rel grad error vs per-rank average={worst:.2e} "

@@ -4,6 +4,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export UNET_AMD_OVERLAP_WGRAD=0     # per-kernel durations without cross-stream queueing (the product default overlaps the weight gradients)
 cd /tmp
 O=$R/gpurun_out/pmc_bench
 rm -rf $O; mkdir -p $O

@@ -814,7 +814,8 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
                "tile count too large for the index arithmetic");
     if constexpr (!DYN && !GEN && !DST && !ACC && KH == 3 && KW == 3 && (WC == 2 || SPEC)) {
         // tile queues (tile_queue.h) for launches with at least three rounds of tiles (two are drawn up front)
-        if (grid == 256 && a.Cin >= 64 && total >= (tileq_level() == 2 ? 256 : tileq_level() == 1 ? 3 * 256 : INT_MAX)) {
+        if (grid == 256 && a.Cin >= 64 && total >= (tileq_level() == 2 ? 256 : tileq_level() == 1 ? 3 * 256 : INT_MAX)
+            && !tileq_capturing(stream)) {
             a.tq = tileq_next_slot();
             if (a.tq == nullptr) return -3;
             return launch_conv2<WC, GEN, DST, SPEC, KH, KW, ACC, true>(a, stream);

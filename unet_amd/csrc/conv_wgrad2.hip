@@ -440,7 +440,8 @@ static int launch_wgrad2g(WgradArgs a, hipStream_t stream, int nsplit) {
         // tile queues (tile_queue.h): a whole number of workgroups per XCD and channel block, at most 16 channel blocks, and
         // enough tiles per workgroup for the choice to matter
         const int nchan = nco * nci, grid = nsplit * nchan;
-        if (tileq_enabled() && nchan <= 16 && grid % (8 * nchan) == 0 && a.tiles_per_split >= (tileq_level() == 2 ? 2 : 3)) {
+        if (tileq_enabled() && nchan <= 16 && grid % (8 * nchan) == 0 && a.tiles_per_split >= (tileq_level() == 2 ? 2 : 3)
+            && !tileq_capturing(stream)) {
             a.tq = tileq_next_slot();
             if (a.tq == nullptr) return -3;
             return launch_wgrad2g<KH, KW, SH, WT, TH, GEN, SPEC, true>(a, stream, nsplit);

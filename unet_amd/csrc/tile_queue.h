@@ -22,4 +22,6 @@ constexpr int TQ_INVALID = 0x7fffffff;
 
 bool tileq_enabled();                       // UNET_AMD_DYNAMIC_TILES / unet_set_dynamic_tiles
 int tileq_level();                          // 0 off, 1 on for launches with several rounds of tiles, 2 on wherever the kernels allow
+bool tileq_capturing(hipStream_t stream);   // a slot is bound at launch time, so a captured graph would replay one slot from every replay (two replays in
+                                            // flight would share its counters): launches under stream capture keep the static partition
 unsigned* tileq_next_slot();                // device pointer to a zeroed slot on the current device (nullptr on failure)

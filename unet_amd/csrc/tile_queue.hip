@@ -28,6 +28,12 @@ extern "C" int unet_set_dynamic_tiles(int on) {
     return 0;
 }
 
+bool tileq_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) { (void)hipGetLastError(); return true; }     // cannot tell: stay static
+    return st != hipStreamCaptureStatusNone;
+}
+
 unsigned* tileq_next_slot() {
     static std::atomic<unsigned*> base[16];
     static std::atomic<unsigned> seq[16];

@@ -54,10 +54,11 @@ class UNetEngine:
         self.last_saved = None
         # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
         # filling between the big persistent kernels (a wgrad block starts on a CU the moment the dgrad conv's block
-        # there retires; the two cannot share a CU, 134 + 151 KB of LDS).  OFF by default because queued-behind time
-        # then counts into every kernel's measured duration and the per-kernel roofline numbers stop meaning anything;
-        # UNET_AMD_OVERLAP_WGRAD=1 (or engine.overlap_wgrad = True) turns it on.
-        self.overlap_wgrad = os.environ.get("UNET_AMD_OVERLAP_WGRAD", "0") == "1"
+        # there retires; the two cannot share a CU, 134 + 151 KB of LDS).  Results are bit-identical (tested).  ON by
+        # default; per-kernel durations then include time queued behind the other stream's kernel, so measurements that
+        # want clean per-kernel numbers (bench.py's one instrumented step, the rocprof profiles) switch it off:
+        # UNET_AMD_OVERLAP_WGRAD=0 or engine.overlap_wgrad = False.
+        self.overlap_wgrad = os.environ.get("UNET_AMD_OVERLAP_WGRAD", "1") != "0"
         self._side_streams = {}
         self._side_busy = False
 

@@ -57,23 +57,41 @@ class EnsemblePredictor:
         return ens, ops.argmax(l1), ops.argmax(l2)
 
     @torch.no_grad()
-    def evaluate(self, loader: Iterable, device, num_classes: Optional[int] = None) -> Dict[str, float]:
-        """Pixel accuracy of model 1, model 2 and the ensemble over a loader of (x, y) batches, from per-batch confusion
-        counts (`unet_seg_counts`); y may be [N,H,W] or [N,1,H,W]."""
-        hit = {"model1": 0, "model2": 0, "ensemble": 0}
+    def evaluate(self, loader: Iterable, device, num_classes: Optional[int] = None) -> Dict[str, object]:
+        """Accuracies of model 1, model 2 and the ensemble over a loader of (x, y) batches, from per-batch confusion counts
+        (`unet_seg_counts`); y may be [N,H,W] or [N,1,H,W].  Returns {"Model1" | "Model2" | "Ensemble": {"overall",
+        "per_class"}} with the reference's definitions (eval_ensemble.py:22-30,123-130: overall = mean(pred == target),
+        per_class[c] = correct_c / max(total_c, 1) over the pixels whose target is c), plus the flat `acc_pixel_*` / `pixels`
+        keys.  The reference's head / medium / tail groups are its CIFAR-LT class split (:113-118) and have no meaning for
+        segmentation classes: not produced.  num_classes defaults to the logits' channel count."""
+        names = ("Model1", "Model2", "Ensemble")
+        conf = None
         total = 0
+        K = num_classes
         for batch in loader:
             x = batch[0].to(device, non_blocking=True)
             y = batch[1].to(device, non_blocking=True)
             if y.ndim == 4:
                 y = y.squeeze(1)
-            ens, p1, p2 = self.predict(x)
-            K = num_classes or 8
-            for name, p in (("model1", p1), ("model2", p2), ("ensemble", ens)):
-                c = ops.seg_counts(p, y.long(), K).tolist()
-                hit[name] += sum(c[k * K + k] for k in range(K))
+            l1, l2 = self.logits(x)
+            if K is None:
+                K = int(l1.shape[1])
+            if conf is None:
+                conf = {n: torch.zeros(K, K, dtype=torch.int64) for n in names}
+            preds = (ops.argmax(l1), ops.argmax(l2), ops.ensemble_fuse(l1, l2, self.entropy_thresh))
+            for name, p in zip(names, preds):
+                c = ops.seg_counts(p, y.long(), K).cpu()
+                conf[name] += c[:K * K].view(K, K)              # [pred][target]
             total += y.numel()
-        return {f"acc_pixel_{k}": (v / total if total else float("nan")) for k, v in hit.items()} | {"pixels": total}
+        out: Dict[str, object] = {"pixels": total}
+        for name, flat in zip(names, ("model1", "model2", "ensemble")):
+            m = conf[name] if conf is not None else torch.zeros(0, 0, dtype=torch.int64)
+            per_target = m.sum(0)
+            overall = float(m.diag().sum()) / total if total else float("nan")
+            out[name] = {"overall": overall,
+                         "per_class": (m.diag().float() / per_target.clamp(min=1).float()).tolist()}
+            out[f"acc_pixel_{flat}"] = overall
+        return out
 
 
 def build_ensemble(cfg1: dict, state1: Optional[dict], cfg2: dict, state2: Optional[dict], device,

@@ -54,7 +54,7 @@ class AsymmConvBlock(nn.Module):
     def forward(self, x):
         raise ops.UNetHipError("AsymmConvBlock is executed by ReparamUNet.forward on the HIP engine")
 
-    def mergeAsyKernels(self, sqrt="reference"):
+    def mergeAsyKernels(self, sqrt="ieee"):
         if self.mergedFlag:
             return
         if self.norm != "batch":
@@ -88,7 +88,7 @@ class MultiConvBlock(nn.Module):
     def forward(self, x):
         raise ops.UNetHipError("MultiConvBlock is executed by ReparamUNet.forward on the HIP engine")
 
-    def mergeMulKernels(self, sqrt="reference"):
+    def mergeMulKernels(self, sqrt="ieee"):
         if self.mergedFlag:
             return
         for block in self.conv_list:
@@ -187,12 +187,17 @@ class ReparamUNet(SlotCache, nn.Module):
             self.make_deploy_skeleton()
         return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
-    def switch_to_deploy(self, sqrt="reference"):
-        """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels).
-        sqrt="reference" (default): std = sqrt(running_var + eps) is taken with torch's CPU sqrt as the reference does
-        (models/reparm_unet.py:29), every other step is an exactly rounded fp32 operation in the reference's order, so
-        the result is torch.equal to the reference's fold on this host; sqrt="ieee": correctly rounded sqrt on the
-        device (identical on every host; differs from torch's MKL sqrt by one ulp for ~0.7 % of the channels)."""
+    def switch_to_deploy(self, sqrt="ieee"):
+        """Fuse every MultiConvBlock into one Conv2d(k_max) on the GPU (HIP fold kernels); returns self.
+        The reference's mergeBN (models/reparm_unet.py:29) takes std = sqrt(running_var + eps) with torch's sqrt on whatever
+        device the BN buffers live on; every other step is one exactly rounded fp32 operation in the reference's order.
+        sqrt="ieee" (default): correctly rounded sqrt on the device -- what a reference model folded ON THE GPU gets
+        (torch's device sqrt is correctly rounded), identical on every host, no device-to-host sync; parity with a
+        GPU-side reference fold is not pinned by a fixture (no GPU where the goldens are made), the IEEE oracle
+        (oracle/fold_ref.py) is.
+        sqrt="reference": std from torch's CPU sqrt (MKL VML, one ulp off for ~0.7 % of the channels, host dependent) --
+        what a reference model folded on the CPU gets; torch.equal to the committed CPU-made golden when given that
+        host's std table (tests/test_gpu_repunet.py).  A callable supplies any other sqrt."""
         print("[ReparamUNet] Switching to deploy mode (fusing kernels)...")
         for module in list(self.modules()):
             if isinstance(module, MultiConvBlock):
@@ -200,6 +205,7 @@ class ReparamUNet(SlotCache, nn.Module):
         self._engine._packed.clear()
         self.invalidate_slots()
         print("[ReparamUNet] Fusion complete.")
+        return self
 
 
 def build_reparam_unet(**kwargs):

@@ -25,6 +25,7 @@ class FusedAdamW(torch.optim.AdamW):
         self._mt_ws = {}            # device -> (partials fp64, norm_out fp32[2])
         self._pending_clip = None
         self._clip_norm = None
+        self._vetoable = []         # parameters whose step count the last fused step() advanced under a device-side veto
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -123,6 +124,13 @@ class FusedAdamW(torch.optim.AdamW):
             self._veto = None
         return self._clip_norm
 
+    def undo_vetoed_step(self):
+        """The veto element was > 0 when the last clip_and_step() ran, i.e. its update kernels did nothing: take back the
+        host-side step counts they were launched with.  The caller (step_batch) learns the flag at its host sync."""
+        for p in self._vetoable:
+            self.state[p]["step"] -= 1
+        self._vetoable = []
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -162,14 +170,18 @@ class FusedAdamW(torch.optim.AdamW):
                         for p in plist:
                             p.grad.mul_(norm_out[1].to(p.device))
                     norm_out = None
+        veto = getattr(self, "_veto", None)
+        self._vetoable = []
         for group, step, plist in work:
             beta1, beta2 = group["betas"]
             for p in plist:
                 self.state[p]["step"] += 1
+            if veto is not None:
+                self._vetoable += plist
             ops.adamw_step(plist, [p.grad for p in plist], [self.state[p]["exp_avg"] for p in plist],
                            [self.state[p]["exp_avg_sq"] for p in plist], norm_out, norm_out is not None,
                            group["lr"], beta1, beta2, group["eps"], group["weight_decay"], step + 1,
-                           veto=getattr(self, "_veto", None))
+                           veto=veto)
             # the kernels write through raw pointers: tell autograd (and the engines' packed-weight caches)
             touched = plist + [self.state[p]["exp_avg"] for p in plist] + [self.state[p]["exp_avg_sq"] for p in plist]
             if norm_out is not None:

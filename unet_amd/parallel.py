@@ -39,8 +39,28 @@ class BucketReducer:
         self.buckets_launched = 0
         self._flat_cache: Dict[tuple, torch.Tensor] = {}      # (bucket index in this backward, numel, dtype, device) -> flat buffer
         self._bucket_idx = 0
+        self._open = False                # a backward is handing gradients over: first add() ... flush() (end of backward) / finish()
+        self.views_installed = None       # set by DataParallel: are last step's bucket views still some p.grad?
 
     def add(self, names: List[str], tensors: List[torch.Tensor]):
+        if not self._open:
+            # First gradient of a new backward.  The flat buffers are rewritten in place, so (a) nothing of an earlier
+            # backward may still be waiting in them (a backward that was never finished, e.g. an exception between
+            # backward and finish_grad_sync: drop it, its keys would otherwise miss and allocate new flats every step),
+            # and (b) no p.grad may still be a view of them: a second backward before the optimizer step would
+            # overwrite the first micro-step's gradients instead of accumulating into them.
+            if self._pending or self._cur:
+                for *_, work in self._pending:
+                    if work is not None:
+                        work.wait()
+                self._pending, self._cur_names, self._cur, self._cur_bytes = [], [], [], 0
+            self._bucket_idx = 0
+            if self.views_installed is not None and self.views_installed():
+                raise RuntimeError(
+                    "unet_amd.parallel: a second backward arrived while p.grad still holds the previous backward's bucket "
+                    "views; call optimizer.zero_grad(set_to_none=True) between backward passes (gradient accumulation "
+                    "across backward calls is not supported by the in-place buckets)")
+            self._open = True
         for n, t in zip(names, tensors):
             if t is None:
                 continue
@@ -79,14 +99,17 @@ class BucketReducer:
         self.buckets_launched += 1
 
     def flush(self):
-        """All gradients of this backward pass have been handed over: launch the partial last bucket."""
+        """All gradients of this backward pass have been handed over: launch the partial last bucket.  An add() after this
+        belongs to a NEW backward."""
         self._launch()
+        self._open = False
 
     def finish(self, average: bool = True) -> Dict[str, torch.Tensor]:
         """Wait for every bucket; returns {name: gradient view}: the average over ranks, or with average=False the SUM
         (the caller folds 1/world into its clip coefficient and saves the pass)."""
         self._launch()
         self._bucket_idx = 0
+        self._open = False
         out: Dict[str, torch.Tensor] = {}
         for names, shapes, offs, flat, work in self._pending:
             if work is not None:
@@ -118,6 +141,9 @@ class DataParallel(nn.Module):
         module._grad_hook = self.reducer.add
         module._grad_flush = self.reducer.flush
         self.collective = self.reducer.collective
+        self.reducer.views_installed = self._grad_views_installed
+        self._installed: List = []          # [(parameter, bucket view)] of the last finish_grad_sync
+        self._status_work = None
         self._buf_flats: List = []          # [(flat tensor, [buffers that are views of it])] per dtype
         if self.collective:
             self._broadcast([p.data for p in module.parameters()])
@@ -186,16 +212,33 @@ class DataParallel(nn.Module):
             self._sync_buffers()
         return self.module(*args, **kwargs)
 
+    def _grad_views_installed(self) -> bool:
+        return any(p.grad is g for p, g in self._installed)
+
+    def share_status(self, flag: torch.Tensor):
+        """MAX over ranks, in place and asynchronously, of a small status tensor (step_batch: the loss kernel's illegal-label
+        counter).  The fused optimizer tail reads it as its veto, so every rank must see the same value or one rank would skip
+        an update the others apply to the same all-reduced gradients.  finish_grad_sync() waits for it."""
+        if self.collective:
+            self._status_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
+
     def finish_grad_sync(self, average: bool = True):
         """Called after loss.backward(): p.grad <- average over ranks.  average=False leaves the SUM in p.grad and
-        returns the factor still owed (1/world); step_batch hands it to FusedAdamW.clip_and_step(grad_scale=...)."""
+        returns the factor still owed (1/world); step_batch hands it to FusedAdamW.clip_and_step(grad_scale=...).
+        p.grad becomes a view of a bucket that the NEXT backward rewrites in place: callers must drop it with
+        zero_grad(set_to_none=True) (step_batch does) before that backward; a second backward without it raises."""
+        if self._status_work is not None:
+            self._status_work.wait()
+            self._status_work = None
         avg = self.reducer.finish(average)
+        self._installed = []
         for n, g in avg.items():
             p = self._params[n]
             if p.grad is None:
                 continue
             if g.dtype == p.grad.dtype:
                 p.grad = g                  # a contiguous view of the reduced bucket (DDP's gradient_as_bucket_view)
+                self._installed.append((p, g))
             else:
                 p.grad.copy_(g)             # communication dtype differs from the gradient's
         return 1.0 if (average or self.world <= 1) else 1.0 / self.world

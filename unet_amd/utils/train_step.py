@@ -10,7 +10,8 @@ clip + optimizer tail is the fused multi-tensor path;
 the one host sync that fetches `main_loss` also carries the loss kernel's illegal-label counter, so a
 label the reference would have raised on still raises here -- at the end of the step instead of inside loss_fn; with the
 fused optimizer tail the same counter vetoes the update on the device, so the bad batch changes neither weights nor
-optimizer moments (as in the reference, where the raise comes before backward).
+optimizer moments nor Adam's step count (as in the reference, where the raise comes before backward); under
+unet_amd.parallel.DataParallel the counter is first MAX-reduced over the ranks, so all of them veto and raise together.
 """
 from contextlib import nullcontext
 from typing import Any, Dict, Tuple
@@ -43,6 +44,13 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
             if batch_idx == 0:
                 trainer.logger.debug(f"Step | Y Squeezed: {y.shape}")
         main_loss = trainer.loss_fn(logits, y)
+
+    # data parallel: the illegal-label counter becomes the MAX over ranks (asynchronously, under backward), so that the
+    # veto below and the error at the end of the step are the same on every rank
+    status = getattr(main_loss, "_unet_status", None)
+    share = getattr(trainer.model, "share_status", None)
+    if share is not None and status is not None and status.numel() >= 4:
+        share(status[3:4])
 
     scaler.scale(main_loss).backward()
     fused = getattr(trainer.optimizer, "clip_and_step", None)
@@ -82,6 +90,11 @@ def step_batch(trainer, x: torch.Tensor, y: torch.Tensor, scaler, batch_idx: int
     if status is not None:
         vals = status.tolist()                      # the step's host sync
         if vals[3] > 0:
+            # the update kernel saw the same flag and did nothing: take back the host-side Adam step count as well, so a
+            # caller that catches this and skips the batch continues with the bias correction of the updates that ran
+            undo = getattr(trainer.optimizer, "undo_vetoed_step", None)
+            if use_fused and undo is not None:
+                undo()
             raise RuntimeError("Class values must be smaller than num_classes.")
         info["main_loss"] = vals[0]
     else:
