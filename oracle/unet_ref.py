@@ -133,6 +133,10 @@ def _wire(x, st: State, block, n_levels: int, taps: Optional[dict] = None, emu: 
     skips = skips[::-1]
     for j in range(n_levels):
         x = _ra(F.conv_transpose2d(x, _rw(st[f"ups.{2*j}.weight"], emu), st[f"ups.{2*j}.bias"], stride=2), emu)  # unet.py:53
+        if taps is not None and x.requires_grad:
+            # gradient w.r.t. the ConvTranspose2d output: its per-channel sum is that layer's bias gradient, and tests use
+            # it to state how heavily that sum cancels (conditioning of the comparison)
+            x.register_hook(lambda g, j=j: taps.__setitem__(f"dup{j}", g.detach()))
         s = skips[j]
         if x.shape != s.shape:                                              # unet.py:56-57
             x = F.interpolate(x, size=s.shape[2:], mode="bilinear", align_corners=True)
@@ -182,16 +186,18 @@ def multi_block(x, st: State, p: str, ks: List[int], norm: str, train: bool, nb)
     return y
 
 
-def rep_double_conv(x, st, p, ks, norm, train, nb):
+def rep_double_conv(x, st, p, ks, norm, train, nb, decisions=None, taps=None):
     """reparm_unet.py:162-167."""
-    x = F.relu(multi_block(x, st, p + ".reparam_conv.0", ks, norm, train, nb))
-    x = F.relu(multi_block(x, st, p + ".reparam_conv.2", ks, norm, train, nb))
+    x = _relu(multi_block(x, st, p + ".reparam_conv.0", ks, norm, train, nb), p + ".a", decisions, taps)
+    x = _relu(multi_block(x, st, p + ".reparam_conv.2", ks, norm, train, nb), p + ".b", decisions, taps)
     return x
 
 
-def repunet_forward(x, st: State, kernel_sizes, norm="group", train=True, new_buffers=None):
+def repunet_forward(x, st: State, kernel_sizes, norm="group", train=True, new_buffers=None, taps=None, decisions=None):
+    """decisions / taps: as unet_forward (keys "<block>.a", "<block>.b" for the two ReLUs of a ReparamDoubleConv, "pool<i>")."""
     n = _levels(st)
-    return _wire(x, st, lambda t, p: rep_double_conv(t, st, p, kernel_sizes, norm, train, new_buffers), n)
+    return _wire(x, st, lambda t, p: rep_double_conv(t, st, p, kernel_sizes, norm, train, new_buffers, decisions, taps),
+                 n, taps, False, decisions)
 
 
 # ---------------------------------------------------------------- fold -----------------

@@ -1,0 +1,358 @@
+"""Whole-engine oracle parity at the BENCHMARK's widths AND spatial sizes (BASELINE configs[1], [2], [4]).
+
+tests/test_gpu_realwidth.py compares the engine with the oracle at real widths on 64x64 inputs, where levels 3 / 4 are 8x8 and
+4x4 and take the general kernels.  Here the inputs are 512x512 (UNet), 128x128 (RepUNet [3,5], real widths) and 1024x1024 (the
+ensemble), so every level runs whole 16x32 tiles on the multi-round persistent grids -- the schedule bench.py and
+tools/bench_configs.py time -- and the result is compared with the pinned oracle (oracle/unet_ref.py, oracle/loss_ref.py)
+computed live on the same seeded inputs.  Reference: /root/reference/models/unet.py:41-62, models/reparm_unet.py:194-215,
+losses/segmentation.py:5-27, eval_ensemble.py:77-99.
+
+Tolerances
+  fp32 kernels : logits / loss / BN buffers / every gradient <= 1e-4 relative (max-abs error / max-abs reference per tensor), the
+                 gradients on the linear piece the HIP path evaluated (oracle `decisions`; see tests/test_gpu_realwidth.py), with
+                 every decision on which the free-running oracle disagrees asserted to be a near-tie (<= 2e-5) and rare.
+  bf16 kernels : stated next to each assertion below (BF16_*).  Unlike the 64x64 test the gradients are ALSO bounded free-running
+                 (no pinning): cosine of the concatenated gradient against the fp32 oracle, and the decisions that differ are
+                 asserted to be near-ties at the scale of bf16 rounding, with a ceiling on how many there are.
+"""
+import pytest
+import torch
+
+from test_gpu_realwidth import (FEATURES, _bn_operand_scale, _cosine, _decision_stats, _noise_bias, _oracle, _q, _run_hip,
+                                rell2, relmax, BF16_ARGMAX_AGREE, BF16_FLIP_FRACTION, BF16_GRAD_COSINE_FREE, BF16_GRAD_RELL2_EMU,
+                                BF16_GRAD_RELL2_PINNED, BF16_LOGITS_RELL2, BF16_LOSS_REL, BF16_POOL_FLIP_FRACTION, BF16_TIE_MAX,
+                                BF16_TIE_Q99, BF16_TIE_STEPS_MAX, BF16_TIE_STEPS_Q99)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]: UNet, 512 x 512
+
+@pytest.fixture(scope="module")
+def bench_case():
+    """UNet[64,128,256,512] on 2x1x512x512 (bench.py's model and image size, SURVEY 8(d) synthetic inputs, seed 42): levels
+    512 / 256 / 128 / 64 / 32 -- 2048 ... 8 whole 16x32 tiles per level, several rounds of the 256-workgroup persistent grid at
+    the upper ones."""
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(42)
+    m = REGISTRY["unet"](in_channels=1, n_classes=2, features=FEATURES)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(2, 1, 512, 512, generator=g)
+    y = (torch.rand(2, 512, 512, generator=g) > 0.95).long()
+    taps = {}
+    free = _oracle(x, y, state, taps=taps)
+    return m, state, x, y, free, taps
+
+
+def test_unet_512_fp32_vs_oracle(dev, bench_case):
+    m, state, x, y, free, taps = bench_case
+    logits, loss, grads, bufs, post, pool = _run_hip(m, state, x, y, dev, "fp32")
+    total, mags, ptotal, pgaps = _decision_stats(post, pool, taps)
+    flips, pflips = mags.numel(), pgaps.numel()
+    print(f"fp32 512x512: {flips} of {total} ReLU decisions and {pflips} of {ptotal} pool winners differ from the free-running "
+          f"oracle; largest flipped magnitude {float(mags.max()) if flips else 0:.2e}, largest winner gap {float(pgaps.max()) if pflips else 0:.2e}")
+    assert flips <= 2e-5 * total and pflips <= 2e-5 * ptotal
+    assert (flips == 0 or float(mags.max()) <= 2e-5) and (pflips == 0 or float(pgaps.max()) <= 2e-5)
+    ref_logits, ref_loss = free[0], free[1]
+    assert relmax(logits, ref_logits) < 1e-4
+    assert abs(loss - ref_loss) < 1e-4 * abs(ref_loss)
+    am = logits.argmax(1) == ref_logits.argmax(1)            # argmax: equal wherever the oracle's two logits are not within rounding
+    near = (ref_logits[:, 0] - ref_logits[:, 1]).abs() < 1e-4 * float(ref_logits.abs().max())
+    assert bool((am | near).all()) and float(am.float().mean()) > 0.9999
+    for k, b in bufs.items():
+        r = free[3][k]
+        if r.dtype == torch.int64:
+            assert torch.equal(b, r), k
+        else:
+            assert relmax(b, r) < 1e-5, k
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    del post
+    ptaps = {}
+    pin_logits, _, ref_grads, _ = _oracle(x, y, state, decisions=dec, taps=ptaps)
+    assert relmax(pin_logits, ref_logits) < 1e-5
+    gmax = max(float(v.abs().max()) for v in ref_grads.values())
+    worst = ("", 0.0)
+    for k, gk in grads.items():
+        r = ref_grads[k]
+        if _noise_bias(k):
+            assert float((gk - r).abs().max()) < 1e-5 * gmax, k
+        elif k.startswith("ups.") and k.endswith(".bias") and ".double_conv." not in k:
+            # ConvTranspose2d bias: the sum over all N*H*W pixels of a gradient field that the BatchNorm backward above it has
+            # made (almost) zero-mean per channel -- a cancelling sum (2 x 512 x 512 = 524 288 terms per channel at the top
+            # level; measured sum|terms| / |sum| >= 2e3 there).  The BatchNorm backward subtracts per-channel means from every
+            # pixel, so the fp32 rounding of those means is COMMON to all terms and adds up linearly: both evaluations carry an
+            # uncertainty of about one ulp of sum|terms| (measured: relmax 2.0e-5 / 3.6e-5 / 8.7e-5 / 1.15e-4 at 8 k / 33 k /
+            # 131 k / 524 k terms).  Bound per channel: 1e-4 of the tensor's maximum plus 2 ulp (2 * 2^-24) of sum|terms|,
+            # the ordinary backward-error bound of a sum; the log line shows both parts.
+            d = ptaps[f"dup{int(k.split('.')[1]) // 2}"]
+            cnt = d.numel() // d.shape[1]
+            sabs = d.abs().double().sum((0, 2, 3))
+            allow = 1e-4 * float(r.abs().max()) + 2 * 2.0 ** -24 * sabs
+            err = (gk - r).abs().double()
+            print(f"{k}: relmax {float(err.max()) / float(r.abs().max()):.2e}; sum of {cnt} terms per channel, sum|terms| / |sum| >= "
+                  f"{float((sabs / r.abs().double().clamp_min(1e-30)).min()):.1e}; worst err / allowance {float((err / allow).max()):.2f}")
+            assert bool((err <= allow).all()), k
+        else:
+            e = relmax(gk, r)
+            if e > worst[1]:
+                worst = (k, e)
+            assert e < 1e-4, (k, e)
+    keys = [k for k in grads if not _noise_bias(k)]
+    print(f"fp32 512x512: logits relmax {relmax(logits, ref_logits):.2e}, worst pinned grad relmax {worst[1]:.2e} ({worst[0]}); "
+          f"free-running gradient cosine {_cosine(grads, free[2], keys):.8f}")
+    m.cpu()
+
+
+def test_unet_512_bf16_vs_oracle(dev, bench_case):
+    m, state, x, y, free, taps = bench_case
+    logits, loss, grads, _, post, pool = _run_hip(m, state, x, y, dev, "bf16")
+    ref_logits, ref_loss, free_grads = free[0], free[1], free[2]
+    e_log = rell2(logits, ref_logits)
+    e_loss = abs(loss - ref_loss) / abs(ref_loss)
+    agree = float((logits.argmax(1) == ref_logits.argmax(1)).float().mean())
+    total, mags, ptotal, pgaps = _decision_stats(post, pool, taps)
+    shapes = {k: v.shape for k, v in post.items()}
+    osc = _bn_operand_scale(state, free[3], lambda blk: shapes[blk + ".a"][0] * shapes[blk + ".a"][2] * shapes[blk + ".a"][3])
+    _, steps, _, _ = _decision_stats(post, {}, taps, operand_scale=osc)
+    steps = steps * 256.0
+    keys = [k for k in grads if not _noise_bias(k)]
+    cos_free = _cosine(grads, free_grads, keys)
+    worst_free = max(((rell2(grads[k], free_grads[k]), k) for k in keys))
+    print(f"bf16 512x512: logits rel-L2 {e_log:.3e}, loss rel {e_loss:.3e}, argmax agreement {agree:.5f}; "
+          f"{mags.numel()} of {total} ReLU decisions ({mags.numel() / total:.3%}) differ from the fp32 oracle, magnitude "
+          f"median {_q(mags, 0.5):.2e} / q99 {_q(mags, 0.99):.2e} / max {_q(mags, 1.0):.2e} = {_q(steps, 0.5):.1f} / {_q(steps, 0.99):.1f} / "
+          f"{_q(steps, 1.0):.1f} bf16 rounding steps of the pre-activation's operands; {pgaps.numel()} of {ptotal} pool winners "
+          f"({pgaps.numel() / ptotal:.3%}), gap q99 {_q(pgaps, 0.99):.2e} / max {_q(pgaps, 1.0):.2e}; free-running gradient cosine "
+          f"{cos_free:.5f}, worst free-running per-tensor rel-L2 {worst_free[0]:.3e} ({worst_free[1]})")
+    assert e_log <= BF16_LOGITS_RELL2 and e_loss <= BF16_LOSS_REL and agree >= BF16_ARGMAX_AGREE
+    assert mags.numel() <= BF16_FLIP_FRACTION * total and pgaps.numel() <= BF16_POOL_FLIP_FRACTION * ptotal
+    assert _q(steps, 0.99) <= BF16_TIE_STEPS_Q99 and _q(steps, 1.0) <= BF16_TIE_STEPS_MAX
+    assert _q(mags, 0.99) <= BF16_TIE_Q99 and _q(mags, 1.0) <= BF16_TIE_MAX
+    assert _q(pgaps, 0.99) <= BF16_TIE_Q99 and _q(pgaps, 1.0) <= BF16_TIE_MAX
+    assert cos_free >= BF16_GRAD_COSINE_FREE
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    del post
+    ptaps = {}
+    _, _, pin_grads, _ = _oracle(x, y, state, decisions=dec, taps=ptaps)
+    # ConvTranspose2d biases: cancelling sums over all pixels of a zero-mean gradient field (see the fp32 test).  With bf16
+    # STORAGE the sum keeps only what the roundings of its terms leave: the oracle's own bf16-storage emulation
+    # (oracle.unet_forward(emulate_bf16=True): rounds exactly where the HIP path stores a tensor) moves these four vectors by
+    # 3e-2 / 6e-2 / 3.3e-1 / 1.2e-1 against the fp32 oracle on the same linear piece -- that is the conditioning of the quantity
+    # under the configured storage type, not a property of the kernels.  They are therefore bounded against the emulating
+    # oracle (below, with every other tensor), and against the fp32 oracle only by 1.5 x the emulation's own distance + 8e-2.
+    tbias = [k for k in keys if k.startswith("ups.") and k.endswith(".bias") and ".double_conv." not in k]
+    worst = max(((rell2(grads[k], pin_grads[k]), k) for k in keys if k not in tbias))
+    print(f"bf16 512x512: worst per-tensor gradient rel-L2 on the same linear piece vs the fp32 oracle {worst[0]:.3e} ({worst[1]})")
+    _, _, emu_grads, _ = _oracle(x, y, state, emulate_bf16=True, decisions=dec)
+    worst_emu = max(((rell2(grads[k], emu_grads[k]), k) for k in keys))
+    print(f"bf16 512x512: worst per-tensor gradient rel-L2 vs the bf16-storage-emulating oracle, same piece {worst_emu[0]:.3e} ({worst_emu[1]})")
+    for k in tbias:
+        e_hip, e_emu = rell2(grads[k], pin_grads[k]), rell2(emu_grads[k], pin_grads[k])
+        print(f"   {k}: vs fp32 oracle {e_hip:.3e} (the emulating oracle itself: {e_emu:.3e}); vs emulating oracle {rell2(grads[k], emu_grads[k]):.3e}")
+        assert e_hip <= 1.5 * e_emu + BF16_GRAD_RELL2_PINNED, k
+    assert worst_emu[0] <= BF16_GRAD_RELL2_EMU, worst_emu
+    assert worst[0] <= BF16_GRAD_RELL2_PINNED, worst
+    m.cpu()
+
+
+def test_unet_full_batch_bf16_vs_fp32_kernels(dev):
+    """The bridge from the 2-image oracle comparison to bench.py's batch: the SAME 32x1x512x512 batch through the bf16 kernels
+    and through the fp32 kernels (which the test above ties to the oracle), train-mode forward + loss: logits rel-L2, loss,
+    argmax agreement and the BatchNorm running statistics both runs leave behind."""
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(42)
+    m = REGISTRY["unet"](in_channels=1, n_classes=2, features=FEATURES)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(32, 1, 512, 512, generator=g).to(dev)
+    y = (torch.rand(32, 512, 512, generator=g) > 0.95).long().to(dev)
+    loss_fn = get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)
+    out = {}
+    for mode in ("fp32", "bf16"):
+        m.load_state_dict(state)
+        m = m.to(dev).train()
+        m.compute_dtype = mode
+        with torch.no_grad():
+            lg = m(x)
+            ls = float(loss_fn(lg, y))
+        out[mode] = (lg.float(), ls, {k: b.detach().clone() for k, b in m.named_buffers()})
+        torch.cuda.synchronize()
+    (l32, s32, b32), (l16, s16, b16) = out["fp32"], out["bf16"]
+    e_log = float((l16 - l32).double().norm() / l32.double().norm())
+    agree = float((l16.argmax(1) == l32.argmax(1)).float().mean())
+    e_buf = max(float((b16[k] - b32[k]).abs().max() / b32[k].abs().max().clamp_min(1e-30)) for k in b32 if b32[k].is_floating_point())
+    print(f"32x1x512x512 bf16 vs fp32 kernels: logits rel-L2 {e_log:.3e}, loss {s16:.6f} vs {s32:.6f}, argmax agreement {agree:.5f}, "
+          f"worst BN running-statistic relmax {e_buf:.2e}")
+    assert e_log <= BF16_LOGITS_RELL2 and abs(s16 - s32) <= BF16_LOSS_REL * abs(s32) and agree >= BF16_ARGMAX_AGREE
+    assert e_buf <= 2e-2
+    assert all(torch.equal(b16[k], b32[k]) for k in b32 if not b32[k].is_floating_point())
+    m.cpu()
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]: RepUNet [3,5]
+
+def _rep_decisions(engine):
+    from unet_amd import ops
+    sv = engine.last_saved
+    nchw = lambda act: act.buf[..., act.off:act.off + act.C].float().cpu().permute(0, 3, 1, 2).contiguous()
+    post, pool = {}, {}
+    for p, (r1, r2) in sv.blocks.items():
+        post[p + ".a"], post[p + ".b"] = nchw(r1.y), nchw(r2.y)
+    for i in range(len(engine.features)):
+        pool[f"pool{i}"] = ops.pool_indices_int64(sv.codes[i], sv.cats[i].shape[2]).cpu()
+    return post, pool
+
+
+def test_repunet_real_widths_train_step_vs_oracle(dev):
+    """ReparamUNet as repar_unet_ct_segmentation.yaml builds it (GroupNorm, kernel_sizes [3,5], features [64,128,256,512]:
+    159.7 M parameters), 1x1x128x128, forward + Dice/CE + backward against oracle.repunet_forward computed live; fp32 kernels
+    to 1e-4 (gradients on the HIP path's linear piece, flipped decisions asserted near-ties), bf16 kernels to the stated bounds."""
+    from oracle import loss_ref, unet_ref
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    ks = [3, 5]
+    torch.manual_seed(42)
+    m = REGISTRY["reparam_unet"](in_channels=1, n_classes=2, features=FEATURES, kernel_sizes=ks)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(42)
+    x = torch.rand(1, 1, 128, 128, generator=g)
+    y = (torch.rand(1, 128, 128, generator=g) > 0.95).long()
+
+    def oracle(decisions=None, taps=None):
+        st = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        lg = unet_ref.repunet_forward(x, st, ks, norm="group", train=True, taps=taps, decisions=decisions)
+        ls = loss_ref.ce_dice(lg, y, 1.0, 1.0, 255)
+        ls.backward()
+        return lg.detach(), float(ls.detach()), {k: v.grad for k, v in st.items()}
+
+    taps = {}
+    ref_logits, ref_loss, free_grads = oracle(taps=taps)
+    loss_fn = get_loss("ce_dice", ce_weight=1.0, dice_weight=1.0, ignore_index=255)
+    m = m.to(dev).train()
+    res = {}
+    for mode in ("fp32", "bf16"):
+        m.compute_dtype = mode
+        m._engine.keep_saved = True
+        m.zero_grad(set_to_none=True)
+        lg = m(x.to(dev))
+        ls = loss_fn(lg, y.to(dev))
+        ls.backward()
+        post, pool = _rep_decisions(m._engine)
+        m._engine.keep_saved = False
+        m._engine.last_saved = None
+        res[mode] = (lg.detach().float().cpu(), float(ls.detach()), {k: p.grad.detach().cpu() for k, p in m.named_parameters()}, post, pool)
+    # fp32
+    lg, ls, grads, post, pool = res["fp32"]
+    total, mags, ptotal, pgaps = _decision_stats(post, pool, taps)
+    assert mags.numel() <= 2e-5 * total + 2 and (mags.numel() == 0 or float(mags.max()) <= 2e-5)
+    assert pgaps.numel() <= 2e-5 * ptotal + 2 and (pgaps.numel() == 0 or float(pgaps.max()) <= 2e-5)
+    assert relmax(lg, ref_logits) < 1e-4 and abs(ls - ref_loss) < 1e-4 * abs(ref_loss)
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    _, _, pin_grads = oracle(decisions=dec)
+    worst = max(((relmax(grads[k], pin_grads[k]), k) for k in grads))
+    print(f"RepUNet [3,5] real widths fp32: {mags.numel()} of {total} ReLU flips, {pgaps.numel()} pool flips; logits relmax "
+          f"{relmax(lg, ref_logits):.2e}, worst pinned grad relmax {worst[0]:.2e} ({worst[1]}), free-running gradient cosine "
+          f"{_cosine(grads, free_grads, list(grads)):.8f}")
+    assert worst[0] < 1e-4, worst
+    # bf16
+    lg, ls, grads, post, pool = res["bf16"]
+    total, mags, ptotal, pgaps = _decision_stats(post, pool, taps)
+    e_log, e_loss = rell2(lg, ref_logits), abs(ls - ref_loss) / abs(ref_loss)
+    cos_free = _cosine(grads, free_grads, list(grads))
+    dec = {k: v > 0 for k, v in post.items()}
+    dec.update(pool)
+    _, _, pin_grads = oracle(decisions=dec)
+    worst = max(((rell2(grads[k], pin_grads[k]), k) for k in grads))
+    print(f"RepUNet [3,5] real widths bf16: logits rel-L2 {e_log:.3e}, loss rel {e_loss:.3e}; {mags.numel()} of {total} ReLU decisions "
+          f"differ (q99 {_q(mags, 0.99):.2e}, max {_q(mags, 1.0):.2e}); free-running gradient cosine {cos_free:.5f}; worst pinned "
+          f"per-tensor rel-L2 {worst[0]:.3e} ({worst[1]})")
+    assert e_log <= BF16_LOGITS_RELL2 and e_loss <= BF16_LOSS_REL
+    assert mags.numel() <= BF16_FLIP_FRACTION * total and _q(mags, 0.99) <= BF16_TIE_Q99 and _q(mags, 1.0) <= BF16_TIE_MAX
+    assert cos_free >= BF16_GRAD_COSINE_FREE and worst[0] <= BF16_GRAD_RELL2_PINNED
+    m.cpu()
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]: ensemble, 1024 x 1024
+
+@pytest.fixture(scope="module")
+def ensemble_case():
+    """UNet (eval) + BatchNorm-variant ReparamUNet [3,5] (to be deployed: 5x5 convs) at the real widths with trained-looking
+    running statistics, one 1024x1024 slice; the oracle's two logit maps (fp32 CPU, ~6 TFLOP)."""
+    from oracle import unet_ref
+    from unet_amd.models import REGISTRY
+    gen = torch.Generator().manual_seed(6)
+
+    def randomise(st):
+        for k in st:
+            if k.endswith("running_mean"):
+                st[k] = torch.randn(st[k].shape, generator=gen) * 0.1
+            elif k.endswith("running_var"):
+                st[k] = torch.rand(st[k].shape, generator=gen) + 0.5
+        return st
+
+    torch.manual_seed(5)
+    u = REGISTRY["unet"](in_channels=1, n_classes=2, features=FEATURES)
+    ust = randomise({k: v.clone() for k, v in u.state_dict().items()})
+    u.load_state_dict(ust)
+    r = REGISTRY["reparam_unet"](in_channels=1, n_classes=2, features=FEATURES, kernel_sizes=[3, 5], norm="batch")
+    rst = randomise({k: v.clone() for k, v in r.state_dict().items()})
+    r.load_state_dict(rst)
+    x = torch.rand(1, 1, 1024, 1024, generator=torch.Generator().manual_seed(42))
+    with torch.no_grad():
+        ref1 = unet_ref.unet_forward(x, ust, train=False)
+        folded = unet_ref.fold_state({k: v.clone() for k, v in rst.items()}, [3, 5])
+        ref2 = unet_ref.repunet_forward(x, folded, [3, 5], norm="batch", train=False)
+    del folded
+    return u, r, x, ref1, ref2
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_ensemble_1024_real_widths_vs_oracle(dev, ensemble_case, amp):
+    """eval_ensemble.py:61-99 as tools/bench_configs.py --workload ensemble runs it, on a 1x1x1024x1024 slice: members' logits
+    against the oracle's (fp32 kernels <= 1e-4; bf16: rel-L2 <= 2e-2), and the fused prediction for entropy_thresh 0.6 (the
+    reference's default) and 0.05 (exercises the override branches on random-init members)."""
+    from oracle import loss_ref
+    from test_gpu_ensemble import _fragile
+    from unet_amd.ensemble import EnsemblePredictor
+    u, r, x, ref1, ref2 = ensemble_case
+    u, r = u.to(dev).eval(), r.to(dev).eval()
+    if any(".conv_list." in k for k in r.state_dict()):
+        r.switch_to_deploy()
+    ens = EnsemblePredictor(u, r, entropy_thresh=0.6, amp=amp)
+    l1, l2 = ens.logits(x.to(dev))
+    l1c, l2c = l1.cpu(), l2.cpu()
+    if not amp:
+        assert relmax(l1c, ref1) < 1e-4 and relmax(l2c, ref2) < 1e-4
+    else:
+        print(f"bf16 members at 1024x1024 vs fp32 oracle: rel-L2 {rell2(l1c, ref1):.3e} (UNet), {rell2(l2c, ref2):.3e} (deployed RepUNet)")
+        assert rell2(l1c, ref1) <= BF16_LOGITS_RELL2 and rell2(l2c, ref2) <= BF16_LOGITS_RELL2
+    for thresh in (0.6, 0.05):
+        ens.entropy_thresh = thresh
+        pred = ens.predict(x.to(dev), want_members=False).cpu()
+        same_in = loss_ref.ensemble_fuse(l1c, l2c, thresh)          # the rule on the logits the members produced
+        frag = _fragile(l1c, l2c, thresh)
+        assert torch.equal(pred[~frag], same_in[~frag])
+        ref_pred = loss_ref.ensemble_fuse(ref1, ref2, thresh)
+        agree = float((pred == ref_pred).float().mean())
+        over = float(((loss_ref.entropy(torch.softmax(ref1, 1)) - loss_ref.entropy(torch.softmax(ref2, 1))).abs() > thresh).float().mean())
+        print(f"ensemble 1024x1024 {'bf16' if amp else 'fp32'} thresh {thresh}: agreement with the fp32 oracle {agree:.5f}, "
+              f"fragile pixels {float(frag.float().mean()):.4f}, override branch taken on {over:.3f} of the pixels")
+        if not amp:
+            frag_ref = _fragile(ref1, ref2, thresh) | frag
+            assert float(frag_ref.float().mean()) < 0.02
+            assert torch.equal(pred[~frag_ref], ref_pred[~frag_ref])
+        else:
+            assert agree >= 0.97
+    u.cpu(); r.cpu()

@@ -102,9 +102,16 @@ def test_ensemble_evaluate_counts(dev):
     r.switch_to_deploy()
     ens = EnsemblePredictor(u, r, entropy_thresh=0.05, amp=True)
     y = (torch.rand(x.shape[0], x.shape[2], x.shape[3], generator=torch.Generator().manual_seed(3)) > 0.5).long()
-    stats = ens.evaluate([(x, y), (x, y.unsqueeze(1))], dev, num_classes=2)
+    stats = ens.evaluate([(x, y), (x, y.unsqueeze(1))], dev)           # num_classes from the logits' channel count
     pred, p1, p2 = ens.predict(x.to(dev))
     assert stats["pixels"] == 2 * y.numel()
+    # eval_ensemble.py:22-30,123-130: overall = mean(pred == target), per_class[c] = correct_c / max(total_c, 1)
+    for name, p in (("Model1", p1), ("Model2", p2), ("Ensemble", pred)):
+        pc = p.cpu()
+        assert abs(stats[name]["overall"] - float((pc == y).float().mean())) < 1e-9
+        for c in range(2):
+            want = float(((pc == c) & (y == c)).sum()) / max(int((y == c).sum()), 1)
+            assert abs(stats[name]["per_class"][c] - want) < 1e-6
     assert abs(stats["acc_pixel_ensemble"] - float((pred.cpu() == y).float().mean())) < 1e-9
     assert abs(stats["acc_pixel_model1"] - float((p1.cpu() == y).float().mean())) < 1e-9
     assert abs(stats["acc_pixel_model2"] - float((p2.cpu() == y).float().mean())) < 1e-9

@@ -312,6 +312,66 @@ def _decision_report(post, pool, taps, tie_tol):
     return total, flips, pflips
 
 
+def _bn_operand_scale(state, nb, count_of):
+    """Per BN layer key ("<block>.a" / "<block>.b") the per-channel size of the operands of the pre-activation
+    y = scale*z + shift at the kink: 1 + |shift_c| (at y = 0, |scale*z| = |shift|; the 1 is the unit variance of the normalised
+    activation, i.e. the upstream noise scale).  One bf16 rounding step of the stored conv output z moves y by 2^-8 of that.
+    mean and variance of the batch are recovered from the oracle's updated running statistics (momentum 0.1)."""
+    out = {}
+    for k in nb:
+        if not k.endswith(".running_mean"):
+            continue
+        bnp = k[:-len(".running_mean")]
+        blk, idx = bnp.rsplit(".double_conv.", 1)
+        n = count_of(blk)
+        mean = (nb[k] - 0.9 * state[k]) / 0.1
+        var_b = (nb[bnp + ".running_var"] - 0.9 * state[bnp + ".running_var"]) / 0.1 * ((n - 1) / n)
+        scale = state[bnp + ".weight"] / torch.sqrt(var_b + 1e-5)
+        shift = state[bnp + ".bias"] - mean * scale
+        out[blk + (".a" if idx == "1" else ".b")] = 1.0 + shift.abs()
+    return out
+
+
+def _decision_stats(post, pool, taps, operand_scale=None):
+    """-> (#ReLU decisions, magnitudes of the flipped ones, #pool decisions, value gaps of the flipped pool winners).
+    A flipped ReLU decision has one side exactly 0; its magnitude is the other side's value.  A flipped pool decision's gap is
+    the difference between the two winners' values in the oracle's tensor.  operand_scale ({key: per-channel tensor}): the
+    ReLU magnitudes are divided by it (see _bn_operand_scale)."""
+    total, mags, ptotal, pgaps = 0, [], 0, []
+    for key, yh in post.items():
+        yr = taps["relu/" + key].detach()
+        mism = (yh > 0) != (yr > 0)
+        total += mism.numel()
+        if mism.any():
+            mag = torch.maximum(yh.abs(), yr.abs())
+            if operand_scale is not None:
+                mag = mag / operand_scale[key][None, :, None, None]
+            mags.append(mag[mism])
+    for key, idx in pool.items():
+        ri = taps[key]
+        mism = idx != ri
+        ptotal += mism.numel()
+        if mism.any():
+            src = taps[f"skip{int(key[4:])}"].detach().flatten(2)
+            a, b = src.gather(2, idx.flatten(2)), src.gather(2, ri.flatten(2))
+            pgaps.append((a - b).abs()[mism.flatten(2)])
+    cat = lambda ts: torch.cat(ts) if ts else torch.zeros(0)
+    return total, cat(mags), ptotal, cat(pgaps)
+
+
+def _q(t, q):
+    if t.numel() == 0:
+        return 0.0
+    k = min(t.numel(), max(1, int(round(q * t.numel()))))
+    return float(t.flatten().kthvalue(k).values)
+
+
+def _cosine(ga, gb, keys):
+    a = torch.cat([ga[k].double().flatten() for k in keys])
+    b = torch.cat([gb[k].double().flatten() for k in keys])
+    return float((a @ b) / (a.norm() * b.norm()))
+
+
 def test_engine_real_widths_fp32(dev, real_case):
     m, state, x, y, free, taps = real_case
     logits, loss, grads, bufs, post, pool = _run_hip(m, state, x, y, dev, "fp32")
@@ -349,11 +409,29 @@ def test_engine_real_widths_fp32(dev, real_case):
     m.cpu()
 
 
-# Stated bf16 tolerance for the whole model at the benchmark's widths (measured values: DESIGN.md 3.2):
+# Stated bf16 tolerances for the whole model at the benchmark's widths, shared with tests/test_gpu_benchsize.py (512 x 512);
+# measured values: DESIGN.md 3.2
 BF16_LOGITS_RELL2 = 2e-2
 BF16_LOSS_REL = 1e-2
 BF16_ARGMAX_AGREE = 0.995
-BF16_GRAD_RELL2_PINNED = 8e-2     # per parameter tensor, fp32 oracle on the HIP path's linear piece (measured worst: 5.9e-2)
+BF16_GRAD_RELL2_PINNED = 8e-2       # per parameter tensor, fp32 oracle on the HIP path's linear piece (measured worst 7.4e-2)
+BF16_GRAD_RELL2_EMU = 6e-2          # per parameter tensor, bf16-storage-emulating oracle on the same piece (measured worst 4.1e-2)
+BF16_FLIP_FRACTION = 1e-2           # ReLU decisions that differ from the fp32 oracle
+BF16_POOL_FLIP_FRACTION = 2e-2      # pool winners that differ (post-ReLU ties between two zeros do not count: same index rule)
+# A decision may differ only where the pre-activation y = scale*z + shift is within bf16 rounding noise of the kink.  One
+# rounding step of a stored bf16 operand is 2^-8 of its size; the operands of y at y = 0 have size |shift_c| (the stored conv
+# output times its scale) and 1 (unit variance of the normalised activation, which carries the noise of the up to 18 layers
+# above it).  Measured at 512x512 in units of 2^-8 * (1 + |shift_c|): median 1.8, 99th percentile 17, maximum 62 steps of
+# 1.42 M differing decisions (the tail: the noise of a pre-activation scales with the size of the activations under ITS
+# 3x3 window, and single pixels carry activations many times the channel's rms).
+# Asserted: 99 % of the differing decisions within 32 steps, every one within 128; and in absolute terms (RepUNet's GroupNorm
+# branches have no single shift) 99 % below 2^-3 and every one below 2^-1 of the O(1) activation scale.
+BF16_TIE_STEPS_Q99 = 32.0
+BF16_TIE_STEPS_MAX = 128.0
+BF16_TIE_Q99 = 2.0 ** -3
+BF16_TIE_MAX = 2.0 ** -1
+BF16_GRAD_COSINE_FREE_SMALL = 0.95  # the same at 2 x 64 x 64 (tests/test_gpu_realwidth.py)
+BF16_GRAD_COSINE_FREE = 0.999       # concatenated gradient (all tensors but the noise-only biases) vs the FREE-RUNNING fp32 oracle
 
 
 def test_engine_real_widths_bf16(dev, real_case):
@@ -363,26 +441,31 @@ def test_engine_real_widths_bf16(dev, real_case):
     e_log = rell2(logits, ref_logits)
     e_loss = abs(loss - ref_loss) / abs(ref_loss)
     agree = float((logits.argmax(1) == ref_logits.argmax(1)).float().mean())
+    # the decisions that differ from the free-running fp32 oracle: how many, and how close to the kink each one is
+    total, mags, ptotal, pgaps = _decision_stats(post, pool, taps)
+    shapes = {k: v.shape for k, v in post.items()}
+    osc = _bn_operand_scale(state, free[3], lambda blk: shapes[blk + ".a"][0] * shapes[blk + ".a"][2] * shapes[blk + ".a"][3])
+    steps = _decision_stats(post, {}, taps, operand_scale=osc)[1] * 256.0
+    keys = [k for k in grads if not _noise_bias(k)]
+    cos_free = _cosine(grads, free_grads, keys)
     dec = {k: v > 0 for k, v in post.items()}
     dec.update(pool)
-    flips = sum(int(((v > 0) != (taps["relu/" + k].detach() > 0)).sum()) for k, v in post.items())
-    total = sum(v.numel() for v in post.values())
     _, _, pin_grads, _ = _oracle(x, y, state, decisions=dec)
-    worst, worst_free = ("", 0.0), ("", 0.0)
-    for k, gk in grads.items():
-        if _noise_bias(k):
-            continue
-        e = rell2(gk, pin_grads[k])
-        if e > worst[1]:
-            worst = (k, e)
-        ef = rell2(gk, free_grads[k])
-        if ef > worst_free[1]:
-            worst_free = (k, ef)
-    print(f"bf16 real widths: logits rel-L2 {e_log:.3e}, loss rel {e_loss:.3e}, argmax agreement {agree:.5f}; "
-          f"{flips} of {total} ReLU decisions differ from the fp32 oracle; worst grad rel-L2 on the same linear piece "
-          f"{worst[1]:.3e} ({worst[0]}), against the free-running fp32 oracle {worst_free[1]:.3e} ({worst_free[0]})")
+    worst = max(((rell2(grads[k], pin_grads[k]), k) for k in keys))
+    worst_free = max(((rell2(grads[k], free_grads[k]), k) for k in keys))
+    print(f"bf16 real widths 64x64: logits rel-L2 {e_log:.3e}, loss rel {e_loss:.3e}, argmax agreement {agree:.5f}; "
+          f"{mags.numel()} of {total} ReLU decisions ({mags.numel() / total:.3%}) and {pgaps.numel()} of {ptotal} pool winners differ from "
+          f"the fp32 oracle, magnitude q99 {_q(mags, 0.99):.2e} / max {_q(mags, 1.0):.2e} = {_q(steps, 0.99):.1f} / {_q(steps, 1.0):.1f} bf16 "
+          f"rounding steps; free-running gradient cosine {cos_free:.5f}; worst grad rel-L2 on the same linear piece "
+          f"{worst[0]:.3e} ({worst[1]}), against the free-running fp32 oracle {worst_free[0]:.3e} ({worst_free[1]})")
     assert e_log <= BF16_LOGITS_RELL2 and e_loss <= BF16_LOSS_REL and agree >= BF16_ARGMAX_AGREE
-    assert worst[1] <= BF16_GRAD_RELL2_PINNED, worst
+    assert mags.numel() <= BF16_FLIP_FRACTION * total and pgaps.numel() <= BF16_POOL_FLIP_FRACTION * ptotal
+    assert _q(steps, 0.99) <= BF16_TIE_STEPS_Q99 and _q(steps, 1.0) <= BF16_TIE_STEPS_MAX
+    assert _q(mags, 0.99) <= BF16_TIE_Q99 and _q(mags, 1.0) <= BF16_TIE_MAX
+    assert _q(pgaps, 0.99) <= BF16_TIE_Q99 and _q(pgaps, 1.0) <= BF16_TIE_MAX
+    # free-running: 8 192 pixels average far less of the decision noise away than the 524 288 of the 512 x 512 test (0.9999 there)
+    assert cos_free >= BF16_GRAD_COSINE_FREE_SMALL
+    assert worst[0] <= BF16_GRAD_RELL2_PINNED, worst
     m.cpu()
 
 
