@@ -4,7 +4,7 @@ rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB.  MI355X_MICROARCH.md (HBM sect
 counts 64 B per 128-B request of a wide coalesced read, so it is doubled; WRITE_SIZE is exact."""
 import csv, glob, hashlib, json, os, sys, collections
 d = sys.argv[1]
-FILTER = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_v2_kernel"       # substring(s, comma separated: ALL must occur) of the kernels averaged into traffic.json
+FILTER = sys.argv[2] if len(sys.argv) > 2 else "conv3x3_v2_kernel"       # substring(s, ";"-separated: ALL must occur) of the kernels averaged into traffic.json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with open(os.environ.get("UNET_HIP_LIB") or os.path.join(ROOT, "unet_amd", "libunet_hip.so"), "rb") as f:
     BUILD = hashlib.sha256(f.read()).hexdigest()[:12]      # the same id bench.py prints as "build"
@@ -22,7 +22,7 @@ for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1]["FETCH_SIZE"]) - sum(k
     wr = 1024 * sum(v["WRITE_SIZE"]) / nw
     out[k] = {"launches": nf, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
     print(f"{k[:70]:70s} n={nf:4d} read {rd/1e6:9.1f} MB  write {wr/1e6:9.1f} MB per launch")
-conv = [v for k, v in out.items() if all(f in k for f in FILTER.split(","))]
+conv = [v for k, v in out.items() if all(f in k for f in FILTER.split(";"))]
 if conv:
     n = sum(c["launches"] for c in conv)
     tot = sum(c["launches"] * c["hbm_bytes_per_launch"] for c in conv)
