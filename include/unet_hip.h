@@ -87,7 +87,12 @@ int unet_conv_out_bwd(int dtype, const float* dlogits, const void* x, int ldx, i
  * tensor is never stored.  Backward: unet_first_bn_relu_bwd = unet_bn_relu_bwd with that tensor recomputed from x, plus the
  * conv's weight gradient dw (Cout,1,3,3) (dz is not stored: the first conv has no input gradient).  ONE pass over dy: dz is
  * affine in (dy', z) with per-channel coefficients, so dw follows from sum dy'*patch (accumulated next to the BN sums) and
- * the 3x3 patch moments of x (a small kernel of their own).  relu bits as unet_bn_relu_bwd.  acc_ws: 12*Cout + 64 doubles. */
+ * the 3x3 patch moments of x (a small kernel of their own).  relu bits as unet_bn_relu_bwd.  acc_ws: 12*Cout + 64 doubles.
+ * unet_first_stats_moments: the same patch moments give the BatchNorm batch statistics of the first conv without computing its
+ * output (sum z = w.s + n b, sum z^2 = w^T R w + ...): `stats` receives two rows [2][Cout][2] for unet_bn_finalize (value +
+ * rounding remainder), `mom` the 64 doubles that unet_first_bn_relu_bwd takes as `moments` (NULL there: computed again). */
+int unet_first_stats_moments(const float* x, const float* w, const float* bias, int N, int H, int W, int Cout,
+                             double* mom, float* stats, void* stream);
 int unet_first_bn_act(int dtype, int relu, const float* x, const float* w, const float* bias,
                       const float* scale, const float* shift, void* y, int ldy, int yoff,
                       int N, int H, int W, int Cout, void* stream);
@@ -95,7 +100,7 @@ int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int dof
                            const float* x, const float* w, const float* bias,
                            const float* scale, const float* shift, const float* mean, const float* invstd,
                            float* dgamma, float* dbeta, float* dbias, float* dw,
-                           float* c1c2_ws, double* acc_ws, int N, int H, int W, int Cout, void* stream);
+                           float* c1c2_ws, double* acc_ws, const double* moments, int N, int H, int W, int Cout, void* stream);
 /* Last layer (models/unet.py:14-15 of the last DoubleConv + final_conv :39,62), n_classes <= 4.  Forward:
  * logits = W act(scale*z+shift) + b in one pass (y optional, may be NULL).  Backward: unet_bn_relu_bwd with its incoming
  * gradient recomputed per element as W^T dlogits, and final_conv's dw (K,C) / db (K) accumulated from the recomputed

@@ -38,6 +38,18 @@ def test_first_layer_fused_vs_torch(dev, dt, shape):
     rows = ops.conv_first_stats(xh, wd, bd, dt)
     s = rows.double().sum(0).cpu()
     close(s[:, 0].float(), z.detach().double().sum((0, 2, 3)).float(), dt, "stats-only sum", f32_out=True)
+    # the same statistics from the image's 3x3 patch moments (what the engine uses: no conv output is computed at all):
+    # mean and variance against an fp64 evaluation of the reference's formula, to 1e-6 of a standard deviation / 1e-5 relative
+    rows_m, mom = ops.first_stats_moments(xh, wd, bd)
+    assert tuple(rows_m.shape) == (2, Cout, 2) and float(mom[54]) == N * H * W
+    sm = rows_m.double().sum(0).cpu()
+    z64 = F.conv2d(x.double(), w.detach().double(), b.detach().double(), padding=1)
+    n = N * H * W
+    mean64, var64 = z64.mean((0, 2, 3)), z64.var((0, 2, 3), unbiased=False)
+    mean_m = sm[:, 0] / n
+    var_m = sm[:, 1] / n - mean_m * mean_m
+    assert float(((mean_m - mean64).abs() / var64.sqrt()).max()) <= 1e-6
+    assert float(((var_m - var64).abs() / var64).max()) <= 1e-5
     st = ops.bn_finalize(rows, N * H * W, gamma.detach().to(dev), beta.detach().to(dev), None, None, None, 0.1, 1e-5, ws)
     ya = ops.Act(torch.zeros((N, H, W, Cout + 8), dtype=ops.torch_dtype(dt), device=dev), 8, Cout)
     ops.first_bn_act(xh, wd, bd, st, ya)
@@ -49,6 +61,9 @@ def test_first_layer_fused_vs_torch(dev, dt, shape):
         assert float((from_act(ya) - ref_y).abs().max()) <= 2 ** -7 * float(ref_y.abs().max())
     assert float(ya.buf[..., :8].float().abs().max()) == 0.0
     dg, db_, dbias, dw = ops.first_bn_relu_bwd(to_act(dyv, dt, dev), xh, wd, bd, st, ws)
+    # handing the forward's moments over gives the same numbers as letting the backward compute them (fp64 atomics: to rounding)
+    dgm, dbm, _, dwm = ops.first_bn_relu_bwd(to_act(dyv, dt, dev), xh, wd, bd, st, ws, moments=mom)
+    assert torch.equal(dgm, dg) and torch.equal(dbm, db_) and float((dwm - dw).abs().max()) <= 1e-6 * float(dw.abs().max())
     if dt == 0:
         # bf16: the batch statistics come from the fp32 conv output while the normalised tensor is its bf16 rounding, so a
         # few ReLU decisions differ from torch's and each moves a per-channel sum by ~1/sqrt(n); the bf16 backward is
@@ -130,7 +145,10 @@ def test_last_layer_fused_vs_torch(dev, dt, geom):
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_engine_with_and_without_fused_edges(dev, mode):
     """Whole model: the fused ends give the same logits bit for bit and the same gradients up to the order of fp64 atomic
-    adds as the separate kernels (train mode and eval-with-gradients)."""
+    adds as the separate kernels (train mode and eval-with-gradients).  Bit equality needs the same statistics on both sides, so
+    this comparison runs the fused first layer with the statistics-only conv pass (first_stats_moments = False); the
+    patch-moment statistics the engine uses by default are checked against fp64 in test_first_layer_fused_vs_torch and
+    against the oracle in every whole-model test."""
     from unet_amd.losses import get_loss
     from unet_amd.models import REGISTRY
     torch.manual_seed(3)
@@ -147,12 +165,14 @@ def test_engine_with_and_without_fused_edges(dev, mode):
             m.load_state_dict(state)
             m.train(training)
             m._engine.fuse_edges = fused
+            m._engine.first_stats_moments = False
             m.zero_grad(set_to_none=True)
             lg = m(x)
             loss_fn(lg, y).backward()
             outs.append((lg.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
                          {k: b.clone() for k, b in m.named_buffers()}))
         m._engine.fuse_edges = True
+        m._engine.first_stats_moments = True
         assert torch.equal(outs[0][0], outs[1][0])
         for k in outs[0][2]:
             assert torch.equal(outs[0][2][k], outs[1][2][k]), k

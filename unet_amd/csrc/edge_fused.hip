@@ -204,14 +204,17 @@ static __global__ void first1_store_kernel(const double* __restrict__ dbacc, con
 // u_p the zero-padded 3x3 patch of pixel p.  mom[55] fp64, accumulated with one atomic per value and workgroup.
 __global__ __launch_bounds__(256) void first1_moments_kernel(const float* __restrict__ x, int N, int H, int W, double* __restrict__ mom) {
     constexpr int PX = 4;                      // consecutive pixels of a row per thread: 18 loads for 4 patches
-    __shared__ float part[4][55];
+    __shared__ double part[4][55];
     const int Wg = (W + PX - 1) / PX;
     const long long groups = (long long)N * H * Wg;
-    float s[9], r[45], cnt = 0.f;
+    // fp64 accumulators: a product of two floats is exact in double, so the only rounding is the fp64 accumulation.  The
+    // forward statistics (first1_stats_from_moments_kernel) take a variance out of these sums by cancellation; the kernel is
+    // bound by its loads, not by the 54 double FMAs per pixel.
+    double s[9], r[45], cnt = 0.0;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
+    for (int t = 0; t < 9; ++t) s[t] = 0.0;
 #pragma unroll
-    for (int t = 0; t < 45; ++t) r[t] = 0.f;
+    for (int t = 0; t < 45; ++t) r[t] = 0.0;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < groups; q += (long long)gridDim.x * 256) {
         const int wg = (int)(q % Wg);
         const long long t1 = q / Wg;
@@ -233,29 +236,54 @@ __global__ __launch_bounds__(256) void first1_moments_kernel(const float* __rest
 #pragma unroll
         for (int px = 0; px < PX; ++px) {
             if (w0 + px >= W) break;
-            cnt += 1.f;
-            float u[9];
+            cnt += 1.0;
+            double u[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) u[t] = win[t / 3][px + t % 3];
+            for (int t = 0; t < 9; ++t) u[t] = (double)win[t / 3][px + t % 3];
             int k = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 s[t] += u[t];
 #pragma unroll
-                for (int t2 = t; t2 < 9; ++t2) { r[k] = fmaf(u[t], u[t2], r[k]); ++k; }
+                for (int t2 = t; t2 < 9; ++t2) { r[k] = fma(u[t], u[t2], r[k]); ++k; }
             }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 55; ++i) {
-        float v = i < 9 ? s[i] : (i < 54 ? r[i < 54 ? i - 9 : 0] : cnt);
+        double v = i < 9 ? s[i] : (i < 54 ? r[i < 54 ? i - 9 : 0] : cnt);
         for (int st = 32; st >= 1; st >>= 1) v += __shfl_xor(v, st);
         if (lane == 0) part[wave][i] = v;
     }
     __syncthreads();
     if (threadIdx.x < 55)
-        atomicAdd(&mom[threadIdx.x], (double)part[0][threadIdx.x] + (double)part[1][threadIdx.x] + (double)part[2][threadIdx.x] + (double)part[3][threadIdx.x]);
+        atomicAdd(&mom[threadIdx.x], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// BatchNorm batch statistics of the first conv from the patch moments: z = w.u + b is linear in the pixel's 3x3 patch u, so
+//   sum_p z = w.s + n b,   sum_p z^2 = w^T R w + 2 b (w.s) + n b^2
+// -- 9 + 45 accumulators per pixel (first1_moments_kernel) instead of all Cout channels of conv3x3(x) computed only to be summed
+// (VALU-bound: 257 us against 73 us at 32x512x512, 64 channels).  fp64 throughout; the two sums leave as TWO fp32 rows (value and
+// the rounding remainder) so that the fp64 row sum of unet_bn_finalize sees ~48 bits of them.  The statistics are those of the
+// UNROUNDED conv output; the bf16 path normalises round_bf16(z), whose rounding is unbiased and averages out over the pixels.
+__global__ __launch_bounds__(256) void first1_stats_from_moments_kernel(const double* __restrict__ mom, const float* __restrict__ w,
+                                                                        const float* __restrict__ bias, int C, float* __restrict__ rows) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double n = mom[54], b = bias != nullptr ? (double)bias[c] : 0.0;
+    double wc[9], ws = 0.0, q = 0.0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wc[t] = (double)w[c * 9 + t]; ws += wc[t] * mom[t]; }
+    int k = 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int t2 = t; t2 < 9; ++t2) { q += (t2 == t ? 1.0 : 2.0) * wc[t] * wc[t2] * mom[k]; ++k; }
+    const double S1 = ws + n * b, S2 = q + 2.0 * b * ws + n * b * b;
+    const float h1 = (float)S1, h2 = (float)S2;
+    rows[c * 2] = h1; rows[c * 2 + 1] = h2;
+    rows[(C + c) * 2] = (float)(S1 - (double)h1); rows[(C + c) * 2 + 1] = (float)(S2 - (double)h2);
 }
 
 // Everything the first layer's backward returns, from pass 3's sums and the input's patch moments.  With d = dy' (ReLU-masked),
@@ -510,11 +538,32 @@ extern "C" int unet_first_bn_act(int dtype, int relu, const float* x, const floa
     return 0;
 }
 
+static int launch_first_moments(const float* x, int N, int H, int W, double* mom, hipStream_t s) {
+    const long long groups = (long long)N * H * ((W + 3) / 4);
+    long long mg = (groups + 255) / 256;
+    if (mg > 256) mg = 256;                                     // 55 fp64 atomics per workgroup: keep them few
+    hipLaunchKernelGGL(first1_moments_kernel, dim3((unsigned)mg), dim3(256), 0, s, x, N, H, W, mom);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int unet_first_stats_moments(const float* x, const float* w, const float* bias, int N, int H, int W, int Cout,
+                                        double* mom /* 64 doubles, written */, float* stats /* [2][Cout][2] */, void* stream) {
+    UNET_CHECK(x && w && mom && stats && N > 0 && H > 0 && W > 0 && Cout > 0, "first_stats_moments: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(mom, 0, sizeof(double) * 64, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    if (int rc = launch_first_moments(x, N, H, W, mom, s)) return rc;
+    hipLaunchKernelGGL(first1_stats_from_moments_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, mom, w, bias, Cout, stats);
+    UNET_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff,
                                       const float* x, const float* w, const float* bias,
                                       const float* scale, const float* shift, const float* mean, const float* invstd,
                                       float* dgamma, float* dbeta, float* dbias /* nullable */, float* dw /* [Cout][1][3][3] */,
                                       float* c1c2_ws /* 2*Cout floats */, double* acc_ws /* 12*Cout + 64 doubles */,
+                                      const double* moments /* nullable: the 64 doubles unet_first_stats_moments wrote for this x */,
                                       int N, int H, int W, int Cout, void* stream) {
     if (ef_check(dtype, Cout, "first_bn_relu_bwd")) return -1;
     UNET_CHECK(dy && x && w && scale && shift && mean && invstd && dgamma && dbeta && dw && c1c2_ws && acc_ws, "first_bn_relu_bwd: null argument");
@@ -537,14 +586,11 @@ extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int l
 #define LPD(P, L, A1, A2, A3, A4) do { if (dtype == UNET_BF16) { if (relu) LP(__bf16, true, P, L, A1, A2, A3, A4); else LP(__bf16, false, P, L, A1, A2, A3, A4); } \
                                        else { if (relu) LP(float, true, P, L, A1, A2, A3, A4); else LP(float, false, P, L, A1, A2, A3, A4); } } while (0)
     if (!two_pass) {
-        const long long groups = (long long)N * H * ((W + 3) / 4);
-        long long mg = (groups + 255) / 256;
-        if (mg > 256) mg = 256;                                     // 55 fp64 atomics per workgroup: keep them few
-        hipLaunchKernelGGL(first1_moments_kernel, dim3((unsigned)mg), dim3(256), 0, s, x, N, H, W, mom);
-        UNET_LAUNCH_CHECK();
+        if (moments == nullptr) { if (int rc = launch_first_moments(x, N, H, W, mom, s)) return rc; }
+        const double* mom_use = moments != nullptr ? moments : mom;
         LPD(3, lds1, (const float*)nullptr, (const float*)nullptr, acc_ws, wacc);
         UNET_LAUNCH_CHECK();
-        hipLaunchKernelGGL(first1_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, wacc, mom, w, bias, scale, mean, invstd,
+        hipLaunchKernelGGL(first1_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, wacc, mom_use, w, bias, scale, mean, invstd,
                            frozen, Cout, dgamma, dbeta, dbias, dw);
         UNET_LAUNCH_CHECK();
         return 0;

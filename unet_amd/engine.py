@@ -50,6 +50,9 @@ class UNetEngine:
         # last activation / its gradient are recomputed inside the bandwidth-bound passes instead of stored (plain UNet,
         # in_channels = 1, <= 4 classes; anything else takes the separate kernels).  False: the separate kernels (tests).
         self.fuse_edges = os.environ.get("UNET_AMD_FUSE_EDGES", "1") != "0"
+        # Batch statistics of the fused first layer from the image's 3x3 patch moments (z is linear in the patch): 73 us instead
+        # of 257 us at 32x512x512, and the backward reuses the moments.  UNET_AMD_FIRST_STATS_CONV=1: the statistics-only conv pass.
+        self.first_stats_moments = os.environ.get("UNET_AMD_FIRST_STATS_CONV", "0") != "1"
         self.keep_saved = False      # tests: leave the last forward's saved activations in self.last_saved
         self.last_saved = None
         # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
@@ -163,9 +166,13 @@ class UNetEngine:
             # conv output never stored: statistics-only pass, then conv + BN + ReLU in one pass; backward recomputes it
             N, H, W_, _ = x_f32.shape
             gamma, beta = P[bnp + ".weight"].detach(), P[bnp + ".bias"].detach()
+            mom = None
             if train:
                 self._stats_gen += 1
-                rows = ops.conv_first_stats(x_f32, w.detach(), b.detach(), dt)
+                if self.first_stats_moments:
+                    rows, mom = ops.first_stats_moments(x_f32, w.detach(), b.detach())
+                else:
+                    rows = ops.conv_first_stats(x_f32, w.detach(), b.detach(), dt)
                 st = ops.bn_finalize(rows, N * H * W_, gamma, beta, B[bnp + ".running_mean"], B[bnp + ".running_var"],
                                      B[bnp + ".num_batches_tracked"], 0.1, BN_EPS, ws)
             else:
@@ -178,6 +185,7 @@ class UNetEngine:
                 rec.xin, rec.x_f32, rec.z, rec.st, rec.first = xin, x_f32, None, st, True
                 rec.wname, rec.bname, rec.bnp = wname, bname, bnp
                 rec.fused_first = True
+                rec.moments = mom
             return y, rec
         if first:
             N, H, W_, _ = x_f32.shape
@@ -341,7 +349,8 @@ class UNetEngine:
         if getattr(r1, "fused_first", False):
             # first layer of the network: its conv output is recomputed from the image inside both BN backward passes and
             # the weight gradient comes out of the second one (nothing but the per-channel gradients is written)
-            dg, db_, dbias, dw1 = ops.first_bn_relu_bwd(dy1, r1.x_f32, w1.detach(), P[r1.bname].detach(), r1.st, ws)
+            dg, db_, dbias, dw1 = ops.first_bn_relu_bwd(dy1, r1.x_f32, w1.detach(), P[r1.bname].detach(), r1.st, ws,
+                                                        moments=getattr(r1, "moments", None))
             grads[r1.bnp + ".weight"], grads[r1.bnp + ".bias"], grads[r1.bname], grads[r1.wname] = dg, db_, dbias, dw1
             return None
         z1 = r1.z

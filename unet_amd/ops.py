@@ -346,6 +346,22 @@ def conv_first_stats(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
     return rows
 
 
+def first_stats_moments(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
+    """(BN partial rows [2, Cout, 2], patch moments [64] fp64) of the Cin = 1 3x3 first conv from the 3x3 patch moments of the
+    image: neither the conv output nor its per-channel values are computed (csrc/edge_fused.hip).  The moments go to
+    first_bn_relu_bwd(moments=...), which needs the same 55 numbers."""
+    _need_cuda(x, w)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    if Cin != 1 or tuple(w.shape) != (Cout, 1, 3, 3) or x.dtype != torch.float32 or not x.is_contiguous() \
+            or w.dtype != torch.float32 or not w.is_contiguous():
+        raise UNetHipError("first conv statistics: fp32 [N,H,W,1] input and (Cout,1,3,3) weights expected")
+    rows = torch.empty((2, Cout, 2), dtype=torch.float32, device=x.device)
+    mom = torch.empty(64, dtype=torch.float64, device=x.device)
+    check(lib().unet_first_stats_moments(_p(x), _p(w), _p(bias), N, H, W, Cout, _p(mom), _p(rows), _stream()), "first_stats_moments")
+    return rows, mom
+
+
 def first_bn_act(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], st: "BNState", y: Act, relu=True):
     """y = act(scale * conv3x3(x) + shift) for the Cin = 1 first layer in one pass (the conv output is not stored)."""
     _need_cuda(x, w)
@@ -361,7 +377,7 @@ def first_bn_act(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor],
 
 
 def first_bn_relu_bwd(dy: Act, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], st: "BNState", ws: "Workspace",
-                      relu=True):
+                      relu=True, moments: Optional[torch.Tensor] = None):
     """BN(+ReLU) backward of the fused first layer -> (dgamma, dbeta, dbias, dw (Cout,1,3,3)); nothing else is written."""
     dy.check()
     _need_cuda(x, w)
@@ -377,7 +393,7 @@ def first_bn_relu_bwd(dy: Act, x: torch.Tensor, w: torch.Tensor, bias: Optional[
     dw = torch.empty((Cout, 1, 3, 3), dtype=torch.float32, device=x.device)
     check(lib().unet_first_bn_relu_bwd(dy.dt, _bn_bwd_flags(st, relu), _p(dy.buf), dy.ld, dy.off, _p(x), _p(w), _p(bias),
                                        _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd), _p(g[0]), _p(g[1]), _p(g[2]), _p(dw),
-                                       _p(ws.c1c2), _p(ws.acc), N, H, W, Cout, _stream()), "first_bn_relu_bwd")
+                                       _p(ws.c1c2), _p(ws.acc), _p(moments), N, H, W, Cout, _stream()), "first_bn_relu_bwd")
     return g[0], g[1], g[2], dw
 
 
