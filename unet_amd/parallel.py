@@ -143,7 +143,6 @@ class DataParallel(nn.Module):
         self.collective = self.reducer.collective
         self.reducer.views_installed = self._grad_views_installed
         self._installed: List = []          # [(parameter, bucket view)] of the last finish_grad_sync
-        self._status_work = None
         self._buf_flats: List = []          # [(flat tensor, [buffers that are views of it])] per dtype
         if self.collective:
             self._broadcast([p.data for p in module.parameters()])
@@ -218,18 +217,17 @@ class DataParallel(nn.Module):
     def share_status(self, flag: torch.Tensor):
         """MAX over ranks, in place and asynchronously, of a small status tensor (step_batch: the loss kernel's illegal-label
         counter).  The fused optimizer tail reads it as its veto, so every rank must see the same value or one rank would skip
-        an update the others apply to the same all-reduced gradients.  finish_grad_sync() waits for it."""
+        an update the others apply to the same all-reduced gradients."""
         if self.collective:
-            self._status_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
+            # four bytes: no point in carrying the handle through backward -- the compute stream waits for it here (a stream
+            # dependency, not a host wait), so that everything queued after this call sees the reduced value
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.pg, async_op=True).wait()
 
     def finish_grad_sync(self, average: bool = True):
         """Called after loss.backward(): p.grad <- average over ranks.  average=False leaves the SUM in p.grad and
         returns the factor still owed (1/world); step_batch hands it to FusedAdamW.clip_and_step(grad_scale=...).
         p.grad becomes a view of a bucket that the NEXT backward rewrites in place: callers must drop it with
         zero_grad(set_to_none=True) (step_batch does) before that backward; a second backward without it raises."""
-        if self._status_work is not None:
-            self._status_work.wait()
-            self._status_work = None
         avg = self.reducer.finish(average)
         self._installed = []
         for n, g in avg.items():
