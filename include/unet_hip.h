@@ -175,7 +175,9 @@ int unet_affine_act_pool(int dtype, int relu, const void* z, int ldz, int zoff, 
 /* dz, dgamma, dbeta (and the conv-bias grad = sum dz) from dy and the saved pre-norm z.
  * relu: bit 0 = ReLU after the norm; bit 1 = frozen statistics (model.eval() with gradients enabled: mean / invstd are
  * the running statistics and carry no gradient): dz = scale*dy', dgamma = sum dy'*(z-mean)*invstd, dbeta = sum dy'.
- * acc_ws: 3*C doubles.  c1c2_ws is no longer used (the finalize between the two passes now runs inside the second) and may
+ * bit 2 = acc_ws is already zero (a caller that clears one arena for many calls; otherwise the call clears it itself).
+ * acc_ws: 3*C + 2 doubles (the sums and the second pass's completion counter: its last workgroup writes dbias, there is no
+ * conversion launch).  c1c2_ws is no longer used (the finalize between the two passes now runs inside the second) and may
  * be NULL; the argument stays so that existing callers keep working. */
 int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
                      void* dz, int ldo, int ooff,
@@ -184,7 +186,7 @@ int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, con
                      float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
 /* unet_bn_relu_bwd without its two workspace arguments.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate device memory -- code under HIP graph capture, tight serving / fine-tuning loops, harnesses that
- * forbid hipMalloc.  The 3*C fp64 accumulators and 2*C fp32 coefficients live in a 64 KiB device array inside the library
+ * forbid hipMalloc.  The 3*C + 2 fp64 accumulators and 2*C fp32 coefficients live in a 64 KiB device array inside the library
  * (one copy per GPU, held until the process ends), so C <= 2048 (larger C is rejected with an error; use unet_bn_relu_bwd).
  * The call allocates and frees nothing.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
  * (two streams, two threads) race -- serialise them on one stream.  The first call on a device fetches the array's

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const double* __restrict__ sums, double count, int frozen,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                           long long M, int C, double* __restrict__ dbias_acc) {
+                                                           long long M, int C, double* __restrict__ dbias_acc,
+                                                           float* __restrict__ dbias, unsigned* __restrict__ done) {
     constexpr int EPV = TT<T>::EPV;
     ChanMap m; m.init<T>(C);
     float part[EPV];
@@ -344,6 +345,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
     if (dbias_acc != nullptr) {
         __syncthreads();                                 // everyone has read its coefficients out of the shared area
         block_reduce_to_acc<EPV>(m, part, EPV, C, dbias_acc, 1);
+        // The LAST workgroup to get here converts the finished fp64 sums to the fp32 gradient (a launch of its own before:
+        // 17 per training step).  Only ATOMICS carry the data (device-scope adds above, device-scope loads below), so no cache
+        // has to be written back: a workgroup-scope release waits until this thread's adds have been performed, the barrier
+        // orders them before thread 0's ticket.  (An agent-scope fence here writes the XCD's whole L2 back -- dz was just
+        // streamed through it -- once per workgroup: +3 ms per training step, measured.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __shared__ unsigned ticket;
+        if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
+        __syncthreads();
+        if (ticket == gridDim.x - 1) {
+            for (int c = threadIdx.x; c < C; c += 256)
+                dbias[c] = (float)__hip_atomic_load(&dbias_acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -678,21 +693,23 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
     UNET_CHECK(scale && shift && mean && invstd, "bn_relu_bwd: scale / shift / mean / invstd must not be NULL");
     UNET_CHECK(dy && z && dz && dgamma && dbeta && acc_ws, "bn_relu_bwd: null argument");
-    const int frozen = (relu >> 1) & 1;
+    const int frozen = (relu >> 1) & 1, prezeroed = (relu >> 2) & 1;
     relu &= 1;
     UNET_CHECK(ldd % 8 == 0 && doff % 8 == 0 && ldz % 8 == 0 && zoff % 8 == 0 && ldo % 8 == 0 && ooff % 8 == 0,
                "bn_relu_bwd: strides/offsets must be multiples of 8");
     hipStream_t s = (hipStream_t)stream;
     const int epv = dtype == UNET_BF16 ? 8 : 4, PL = 256 / (C / epv);
     const int grid = grid_for(M, PL);
-    if (hipMemsetAsync(acc_ws, 0, sizeof(double) * 3 * C, s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
+    // 3*C fp64 sums + the apply pass's completion counter; relu bit 2: the caller hands over an area that is already zero
+    // (unet_amd clears ONE arena per backward pass instead of one memset per layer)
+    if (!prezeroed && hipMemsetAsync(acc_ws, 0, sizeof(double) * (3 * C + 2), s) != hipSuccess) { unet_set_error("memset failed"); return -2; }
     const size_t lds1 = reduce_lds_bytes(C / epv, 2 * epv);
     size_t lds2 = reduce_lds_bytes(C / epv, epv);
     if (lds2 < (size_t)2 * C * sizeof(float)) lds2 = (size_t)2 * C * sizeof(float);      // the apply pass parks c1 / c2 there first
     (void)c1c2_ws;            // the finalize that filled it now lives in the apply pass
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
 #define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
-#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, acc_ws, (double)M, frozen, dgamma, dbeta, M, C, dbacc)
+#define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, acc_ws, (double)M, frozen, dgamma, dbeta, M, C, dbacc, dbias, (unsigned*)(acc_ws + 3 * C))
     if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
     else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
     UNET_LAUNCH_CHECK();
@@ -701,10 +718,6 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     UNET_LAUNCH_CHECK();
 #undef LAUNCH_R
 #undef LAUNCH_A
-    if (dbias) {
-        hipLaunchKernelGGL(acc_to_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, s, acc_ws + 2 * C, dbias, C, 0);
-        UNET_LAUNCH_CHECK();
-    }
     return 0;
 }
 
@@ -712,7 +725,7 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
                                 void* dz, int ldo, int ooff,
                                 const float* scale, const float* shift, const float* mean, const float* invstd,
                                 float* dgamma, float* dbeta, float* dbias /* nullable */,
-                                float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
+                                float* c1c2_ws /* unused */, double* acc_ws /* 3*C + 2 doubles */,
                                 long long M, int C, void* stream) {
     return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
                                    scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
@@ -726,7 +739,7 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
 // never a device address: the address is fetched once per device with hipGetSymbolAddress and only that pointer is
 // handed to memsets and kernels.
 #define NOALLOC_MAX_C 2048
-#define NOALLOC_ACC_BYTES (NOALLOC_MAX_C * 3 * sizeof(double))
+#define NOALLOC_ACC_BYTES ((NOALLOC_MAX_C * 3 + 2) * sizeof(double))
 #define NOALLOC_SCRATCH_BYTES (NOALLOC_ACC_BYTES + NOALLOC_MAX_C * 2 * sizeof(float))
 static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
 
@@ -763,7 +776,8 @@ extern "C" int unet_bn_relu_bwd_noalloc(int dtype, int relu, const void* dy, int
                "use unet_bn_relu_bwd with caller workspaces", C, NOALLOC_MAX_C);
     void* ptr = nullptr;
     if (int rc = noalloc_scratch(&ptr)) return rc;
-    double* acc_ws = (double*)ptr;                                             // 3*C doubles, cleared by the shared implementation
+    relu &= 3;                                                                 // the scratch keeps the last call's contents: never "already zero"
+    double* acc_ws = (double*)ptr;                                             // 3*C + 2 doubles, cleared by the shared implementation
     float* c1c2_ws = (float*)((unsigned char*)ptr + NOALLOC_ACC_BYTES);        // 2*C floats, fully rewritten before they are read
     return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
                                    scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
@@ -773,7 +787,7 @@ extern "C" int unet_bn_relu_bwd_pool(int dtype, int relu, const void* dpool, con
                                      const void* z, int ldz, int zoff, void* dz, int ldo, int ooff,
                                      const float* scale, const float* shift, const float* mean, const float* invstd,
                                      float* dgamma, float* dbeta, float* dbias /* nullable */,
-                                     float* c1c2_ws /* 2*C floats */, double* acc_ws /* 3*C doubles */,
+                                     float* c1c2_ws /* unused */, double* acc_ws /* 3*C + 2 doubles */,
                                      int N, int H, int W, int C, void* stream) {
     UNET_CHECK(dpool && code && dskip, "bn_relu_bwd_pool: null argument");
     UNET_CHECK(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bn_relu_bwd_pool: H and W must be even (got %dx%d)", H, W);

@@ -383,6 +383,7 @@ class UNetEngine:
         L = len(self.features)
         dev = dlogits.device
         ws = self.ws(dev)
+        ws.clear_arena()             # one fill for every BatchNorm backward's accumulators of this pass (ops.Workspace)
         grads: Dict[str, torch.Tensor] = {}
 
         def emit(names):
