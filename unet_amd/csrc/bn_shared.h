@@ -29,7 +29,10 @@ static inline size_t reduce_lds_bytes(int G, int NV) {
     return pow2 ? (size_t)4 * (G < 64 ? G : 64) * NV * sizeof(float) : (size_t)256 * NV * sizeof(float);
 }
 
-template <int NV>
+// WAIT = true: the adds are RETURNING atomics and the thread holds on to their results, i.e. it does not leave this function
+// before every one of its adds has been performed at the device's coherence point (a no-return atomic is only queued).  For
+// callers whose workgroup afterwards takes a completion ticket that lets another workgroup read the sums.
+template <int NV, bool WAIT = false>
 __device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const float (&part)[NV], int epv, int C,
                                                     double* acc, int acc_stride /* values per channel */) {
     extern __shared__ float red_lds[];
@@ -59,7 +62,10 @@ __device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const floa
             }
             const int k = r / epv, e = r - k * epv;
             const int c = cg * epv + e;
-            if (c < C) atomicAdd(&acc[c * acc_stride + k], (double)sum);
+            if (c < C) {
+                if constexpr (WAIT) { const double old = atomicAdd(&acc[c * acc_stride + k], (double)sum); asm volatile("" :: "v"(old)); }
+                else atomicAdd(&acc[c * acc_stride + k], (double)sum);
+            }
         }
         return;
     }
@@ -77,7 +83,10 @@ __device__ __forceinline__ void block_reduce_to_acc(const ChanMap& m, const floa
         const int cg = i / NV, r = i - cg * NV;
         const int k = r / epv, e = r - k * epv;
         const int c = cg * epv + e;
-        if (c < C) atomicAdd(&acc[c * acc_stride + k], (double)s);
+        if (c < C) {
+            if constexpr (WAIT) { const double old = atomicAdd(&acc[c * acc_stride + k], (double)s); asm volatile("" :: "v"(old)); }
+            else atomicAdd(&acc[c * acc_stride + k], (double)s);
+        }
     }
 }
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // while the producer issues, and the producer has it while the partner waits at the next barrier: the two
     // waves of a SIMD run in anti-phase by construction instead of stalling on DMA issue side by side.
     constexpr bool ASYM = C::ASYM;
-    static_assert(!SPEC || (WC == 1 && !GEN && !DST), "request waves: 64-channel tiles of the specialised kernel");
+    static_assert(!SPEC || (WC == 1 && !GEN), "request waves: 64-channel tiles of the specialised kernel");
     constexpr int NPROD = (ASYM || SPEC) ? 4 : 8;             // waves that issue DMA
     constexpr int HPW = C::H_PIECES / NPROD;                  // halo pieces per producer wave
     static_assert(C::H_PIECES % NPROD == 0, "halo pieces must divide among the producer waves");
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                 }
                 __syncthreads();
                 push_h();
-                if (a.stats != nullptr) __syncthreads();
+                // statistics: the matrix waves' cross-wave reduction has a second barrier -- per tile, or (one row per
+                // workgroup, DST) on the workgroup's last tile only
+                if (a.stats != nullptr && (!DST || t_i + (int)gridDim.x >= total_tiles)) __syncthreads();
             }
             return;
         }
@@ -451,13 +453,22 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
     // tile, whose stats row then carries the whole workgroup's sums - the rows of its other tiles are written as
     // zeros, so "sum over rows" (all any consumer does with them) is unchanged.  Per tile this removes 32 DPP
     // reductions per wave and two barriers: the forward epilogue of these HBM-bound layers was 2.4x the dgrad one.
+    // With REQUEST WAVES (SPEC) the kernel has to fit three waves per SIMD (168 registers) and cannot afford those 32: there the
+    // 16-lane reduction stays per tile (128 DPP adds per wave, ~3 % of a tile), but its result is ADDED to the wave's private
+    // row of the reduction area instead of being handed to a cross-wave reduction, so the two barriers, the cross-wave sum and
+    // the row store still run once per workgroup and the statistics cost no register across the main loop.
     constexpr bool DEFER = DST;      // own instantiation: the 32 extra live registers cost the launches without statistics 6 %
-    static_assert(!DST || (!GEN && WC == 1), "deferred statistics are for the specialised 64-channel kernel");
-    float run1[DEFER ? 4 : 1][4], run2[DEFER ? 4 : 1][4];
+    constexpr bool DEFER_REG = DST && !SPEC, DEFER_LDS = DST && SPEC;
+    static_assert(!DST || (!GEN && WC == 1 && !DYN), "deferred statistics are for the specialised 64-channel kernel");
+    float run1[DEFER_REG ? 4 : 1][4], run2[DEFER_REG ? 4 : 1][4];
 #pragma unroll
-    for (int i = 0; i < (DEFER ? 4 : 1); ++i)
+    for (int i = 0; i < (DEFER_REG ? 4 : 1); ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { run1[i][r] = 0.f; run2[i][r] = 0.f; }
+    if constexpr (DEFER_LDS) {       // this wave's row [BCO][2] of the reduction area starts at zero (wave-private: no barrier)
+        float* row = (float*)(smem + C::OFF_RED) + wr * BCO * 2;
+        row[lane] = 0.f; row[lane + 64] = 0.f;
+    }
     for (;;) {
         const bool last_tile = tile_i + (int)gridDim.x >= total_tiles;
         if constexpr (DYN) { if (wave == 7) tq_request(); }        // id of tile k+2, collected at this tile's last phase
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                 // pass 1 (forward only): BN partial statistics.  Every lane stores its (sum, sum of squares) pair:
                 // lanes other than the group's first aim at a scratch slot, which is cheaper than sixteen exec-mask
                 // round trips.
-                if (do_stats && (!DEFER || last_tile)) {
+                if (do_stats && (!DEFER_REG || last_tile)) {
                     // one address select per lane; the 16 pairs then go to base + immediate (the scratch slots of
                     // different lanes overlap, which is fine for values nobody reads, and stay on distinct banks)
                     char* sbase = l15e == 0 ? (char*)&red[(wr * BCO + wc * 64 + 4 * ge) * 2]
@@ -632,7 +643,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #pragma unroll
                     for (int ct = 0; ct < 4; ++ct) {
                         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-                        if constexpr (DEFER) {
+                        if constexpr (DEFER_REG) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { s1[r] = run1[ct][r]; s2[r] = run2[ct][r]; }
                         }
@@ -645,12 +656,16 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
                             float2 t;
                             t.x = wave_sum16(s1[r]);
                             t.y = wave_sum16(s2[r]);
+                            if constexpr (DEFER_LDS) {           // running sums of this wave's tiles (scratch lanes add garbage to garbage)
+                                const float2 old = *(const float2*)(sbase + (ct * 16 + r) * 8);
+                                t.x += old.x; t.y += old.y;
+                            }
                             *(float2*)(sbase + (ct * 16 + r) * 8) = t;
                         }
                     }
-                } else if (DEFER && do_stats) {
+                } else if (DEFER_REG && do_stats) {
 #pragma unroll
-                    for (int ct = 0; ct < (DEFER ? 4 : 1); ++ct)
+                    for (int ct = 0; ct < (DEFER_REG ? 4 : 1); ++ct)
 #pragma unroll
                         for (int pg = 0; pg < NPG; ++pg)
 #pragma unroll
@@ -769,6 +784,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
         if (h_owed) { push_h(); h_owed = false; }
         if (DEFER && do_stats && !last_tile) {
             // nothing to write: this tile's sums ride in the workgroup's one statistics row (written on its last tile)
+            if constexpr (SPEC) __syncthreads();        // the request waves may refill the halo stage the epilogue borrowed
         } else if (do_stats) {
             __syncthreads();
             if (tid < BCO * 2) {
@@ -865,8 +881,12 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     // dgrad 0.594 -> 0.554 ms on one box.  (The same kernel on the 128...1024-channel layers, 64 output channels per
     // workgroup, is 2-4 % slower than the 128-channel-tile kernel: 1.35x the DMA bytes per MFMA; with the deferred
     // statistics' 32 extra registers it does not fit three waves per SIMD.)
-    return (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit)) ? launch_conv2<1, false, true>(a, s)
-                                                                                                 : launch_conv2<1, false, false, true>(a, s);
+    // The statistics-carrying forward of the 64-channel layers has request waves as well (round 3; UNET_AMD_DST_NOSPEC=1 selects
+    // the round-2 form with the sums in registers and no request waves, for A/B runs).
+    static const bool dst_nospec = [] { const char* e = getenv("UNET_AMD_DST_NOSPEC"); return e && atoi(e) != 0; }();
+    if (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit))
+        return dst_nospec ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false, true, true>(a, s);
+    return launch_conv2<1, false, false, true>(a, s);
 }
 
 // 5x5 stride 1 on whole 16x32 tiles and whole 64-channel blocks: the LDS-DMA kernel (one stats row per pixel tile); everything

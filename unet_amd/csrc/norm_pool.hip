@@ -344,13 +344,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(PoolSrc ps, const T* 
     }
     if (dbias_acc != nullptr) {
         __syncthreads();                                 // everyone has read its coefficients out of the shared area
-        block_reduce_to_acc<EPV>(m, part, EPV, C, dbias_acc, 1);
+        block_reduce_to_acc<EPV, true>(m, part, EPV, C, dbias_acc, 1);
         // The LAST workgroup to get here converts the finished fp64 sums to the fp32 gradient (a launch of its own before:
         // 17 per training step).  Only ATOMICS carry the data (device-scope adds above, device-scope loads below), so no cache
-        // has to be written back: a workgroup-scope release waits until this thread's adds have been performed, the barrier
-        // orders them before thread 0's ticket.  (An agent-scope fence here writes the XCD's whole L2 back -- dz was just
-        // streamed through it -- once per workgroup: +3 ms per training step, measured.)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // has to be written back; what is needed is that every add has been PERFORMED before thread 0 takes the ticket: the
+        // adds are returning atomics whose results the threads wait for, then the barrier.  Measured alternatives: an
+        // agent-scope fence here writes the XCD's whole L2 back -- dz was just streamed through it -- once per workgroup
+        // (+3 ms per training step); a workgroup-scope fence after no-return adds is not enough (the last workgroup read
+        // sums that other workgroups' queued adds had not reached yet: tests/test_gpu_realwidth.py caught it).
         __syncthreads();
         __shared__ unsigned ticket;
         if (threadIdx.x == 0) ticket = atomicAdd(done, 1u);
