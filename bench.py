@@ -87,7 +87,7 @@ class ConvTimer:
         return self._sum(self.wgrad_records)
 
 
-PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def lib_build_id():
@@ -145,8 +145,8 @@ def cpu_baseline(sample_images=4, size=512, iters=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0,
                     help="per-GPU batch; default 32 on one GPU (configs[1]), 256 // N on N > 1 GPUs (configs[3]: global batch 256)")
     ap.add_argument("--global-batch", type=int, default=256, help="global batch the N > 1 default per-rank batch is derived from")

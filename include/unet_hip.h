@@ -184,6 +184,21 @@ int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, int doff, con
                      const float* scale, const float* shift, const float* mean, const float* invstd,
                      float* dgamma, float* dbeta, float* dbias,
                      float* c1c2_ws, double* acc_ws, long long M, int C, void* stream);
+/* The first pass of unet_bn_relu_bwd inside the kernel that PRODUCES dy: the 3x3 dgrad of a DoubleConv's second conv
+ * (models/unet.py:13 under autograd; w_dgrad = unet_pack_weights mode 1) writes dy and, per 16x32 pixel tile, the rows
+ * (sum dy', sum dy'*xhat) of the BatchNorm + ReLU in front of it (models/unet.py:11-12; z = its saved pre-norm tensor).
+ * unet_bn_relu_bwd_rows then adds the rows up and runs the second pass only.  bf16 and whole tiles / 64-channel blocks
+ * (unet_conv_dgrad_bnred_ok); sum_rows: N*(H/16)*(W/32) rows of [Cout][2] floats. */
+int unet_conv_dgrad_bnred_ok(int dtype, int H, int W, int Cin, int Cout);
+int unet_conv_dgrad_bnred(int dtype, const void* dz, int ldx, int xoff, const void* w_dgrad, void* dy, int ldy, int yoff,
+                          float* sum_rows, const void* z, int ldz, int zoff,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          int N, int H, int W, int Cin, int Cout, void* stream);
+int unet_bn_relu_bwd_rows(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                          void* dz, int ldo, int ooff,
+                          const float* scale, const float* shift, const float* mean, const float* invstd,
+                          float* dgamma, float* dbeta, float* dbias,
+                          const float* sum_rows, int nrows, double* acc_ws, long long M, int C, void* stream);
 /* unet_bn_relu_bwd without its two workspace arguments.  NO COUNTERPART IN THE REFERENCE: it exists for callers that
  * cannot allocate device memory -- code under HIP graph capture, tight serving / fine-tuning loops, harnesses that
  * forbid hipMalloc.  The 3*C + 2 fp64 accumulators and 2*C fp32 coefficients live in a 64 KiB device array inside the library

@@ -193,6 +193,90 @@ def test_conv_transpose_real_widths(dev, dt, shape):
     close(dw.cpu(), wt.grad, dt, "convT wgrad", f32_out=True)
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 64, 64, 64), (1, 32, 32, 128, 128), (1, 16, 64, 256, 256), (1, 16, 32, 512, 512),
+                                   (1, 16, 32, 1024, 1024), (2, 16, 32, 128, 64)])
+def test_dgrad_with_bn_backward_sums_real_widths(dev, shape):
+    """unet_conv_dgrad_bnred: the 3x3 dgrad of a DoubleConv's second conv with the first pass of the BatchNorm backward in front
+    of it in its epilogue (models/unet.py:11-13 under autograd).  dy must be bit-equal to the plain dgrad launch; the sums must
+    equal an fp64 evaluation of sum dy' and sum dy'*xhat on the CPU (from the unrounded dgrad result), to summation noise; and
+    the BatchNorm backward fed with the rows must agree with the two-pass form, which sums the bf16-ROUNDED dy: the difference
+    is that rounding's random walk, bounded here by 6 standard deviations of it."""
+    from unet_amd import ops
+    N, H, W, Cmid, C = shape                # dz has Cmid channels (the conv's outputs), dy / z have C (its inputs)
+    dt = 1
+    dzv = q(rnd((N, Cmid, H, W), 121), dt)
+    w = q(rnd((Cmid, C, 3, 3), 122, (C * 9) ** -0.5), dt)
+    zv = q(rnd((N, C, H, W), 123) * 1.5 + 0.3, dt)
+    gamma, beta = rnd((C,), 124).abs() + 0.5, rnd((C,), 125) * 0.3
+    dy_ref = F.conv_transpose2d(dzv.double(), w.double(), padding=1)         # dgrad of conv2d(pad 1) in fp64
+    n = N * H * W
+    mean, var = zv.double().mean((0, 2, 3)), zv.double().var((0, 2, 3), unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    scale, shift = gamma.double() * invstd, beta.double() - mean * gamma.double() * invstd
+    st = ops.BNState(scale.float().to(dev), shift.float().to(dev), mean.float().to(dev), invstd.float().to(dev))
+    sc, sh, mu, is_ = (t.float().double()[None, :, None, None] for t in (scale, shift, mean, invstd))
+    mask = (zv.double() * sc + sh) > 0
+    xhat = (zv.double() - mu) * is_
+    d = dy_ref * mask
+    S1, S2 = d.sum((0, 2, 3)), (d * xhat).sum((0, 2, 3))
+
+    dza, za = to_act(dzv, dt, dev), to_act(zv, dt, dev)
+    wd = ops.pack_weights(w.to(dev), 1, dt)
+    dy_a, dy_b = ops.dense(N, H, W, C, dt, dev), ops.dense(N, H, W, C, dt, dev)
+    ops.conv_fwd(dza, wd, None, dy_a, 3, 3, Cmid, C)
+    rows = ops.conv_dgrad_bnred(dza, wd, dy_b, za, st)
+    assert rows is not None and tuple(rows.shape) == (N * (H // 16) * (W // 32), C, 2)
+    assert torch.equal(dy_a.buf, dy_b.buf)
+    got = rows.double().sum(0).cpu()
+    # fp32 accumulators over K = 9*Cmid products of bf16 operands, then a sum of n terms: relative to the root sum of squares
+    rss1, rss2 = d.pow(2).sum((0, 2, 3)).sqrt(), (d * xhat).pow(2).sum((0, 2, 3)).sqrt()
+    assert float(((got[:, 0] - S1).abs() / rss1).max()) <= 2e-4, "sum dy'"
+    assert float(((got[:, 1] - S2).abs() / rss2).max()) <= 2e-4, "sum dy' xhat"
+    ws = ops.Workspace(dev)
+    dz_a, dz_b = ops.dense(N, H, W, C, dt, dev), ops.dense(N, H, W, C, dt, dev)
+    dg_a, db_a, _ = ops.bn_relu_bwd(dy_a, za, dz_a, st, ws)
+    dg_b, db_b, dbias_b = ops.bn_relu_bwd(dy_b, za, dz_b, st, ws, sum_rows=rows)
+    assert float(((dg_b.cpu().double() - S2).abs() / rss2).max()) <= 2e-4 and float(((db_b.cpu().double() - S1).abs() / rss1).max()) <= 2e-4
+    walk1, walk2 = 2.0 ** -9 * rss1, 2.0 ** -9 * rss2                       # bf16 storage rounding of dy in the two-pass form
+    assert float(((db_a.cpu().double() - db_b.cpu().double()).abs() / walk1).max()) <= 6.0
+    assert float(((dg_a.cpu().double() - dg_b.cpu().double()).abs() / walk2).max()) <= 6.0
+    assert float((dz_a.buf.float() - dz_b.buf.float()).abs().max()) <= 2.0 ** -6 * float(dz_a.buf.float().abs().max())
+    assert float(dbias_b.abs().max()) <= 2e-2 * float(dy_ref.abs().max()) * n ** 0.5          # noise-only in train mode
+
+
+def test_engine_with_bn_sums_in_dgrad(dev):
+    """The opt-in schedule (UNET_AMD_BN_REDUCE_IN_DGRAD=1 / engine.bn_reduce_in_dgrad): whole bf16 backward with the first pass
+    of every eligible BatchNorm backward inside the producing dgrad.  Same forward; gradients agree with the default schedule to
+    the rounding of dy it skips (the sums see dy before it is stored as bf16): per tensor rel-L2 <= 1e-2."""
+    from unet_amd.losses import get_loss
+    from unet_amd.models import REGISTRY
+    torch.manual_seed(11)
+    m = REGISTRY["unet"](in_channels=1, n_classes=2, features=[64, 128]).to(dev).train()
+    m.compute_dtype = "bf16"
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(2, 1, 64, 128, generator=g).to(dev)
+    y = (torch.rand(2, 64, 128, generator=g) > 0.9).long().to(dev)
+    loss_fn = get_loss("ce_dice", ignore_index=255)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    outs = []
+    for fused in (False, True):
+        m.load_state_dict(state)
+        m._engine.bn_reduce_in_dgrad = fused
+        m.zero_grad(set_to_none=True)
+        lg = m(x)
+        loss_fn(lg, y).backward()
+        outs.append((lg.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+    m._engine.bn_reduce_in_dgrad = False
+    assert torch.equal(outs[0][0], outs[1][0])
+    tbias = lambda k: k.startswith("ups.") and k.endswith(".bias") and ".double_conv." not in k      # cancelling sums (see test_gpu_benchsize)
+    err = {k: rell2(outs[1][1][k].cpu(), outs[0][1][k].cpu()) for k in outs[0][1] if not _noise_bias(k)}
+    worst = max((e, k) for k, e in err.items() if not tbias(k))
+    worst_t = max((e, k) for k, e in err.items() if tbias(k))
+    print(f"BN sums in the dgrad epilogue vs the two-pass form: worst per-tensor gradient rel-L2 {worst[0]:.2e} ({worst[1]}), "
+          f"ConvTranspose2d biases {worst_t[0]:.2e} ({worst_t[1]})")
+    assert worst[0] <= 1e-2 and worst_t[0] <= 5e-2, (worst, worst_t)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # whole engine at the benchmark's widths against the pinned oracle, computed live
 #

@@ -91,12 +91,18 @@ __device__ __forceinline__ int swz64(int idx) { return ((idx >> 2) & 1) << 1; } 
 // tile has at least two chunks, so no cursor reaches tile k+2 before the last chunk of tile k): two are drawn at the start,
 // then matrix wave 7 (it issues no DMA, so its memory counter is free) requests the id of tile k+2 at the top of tile k and
 // collects it at the tile's last phase; the ids travel through four LDS words to the cursors and the request waves.
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false>
+// BNR = true (the 3x3 dgrad of a DoubleConv's second conv, specialised kernel): the FIRST PASS OF THE BATCHNORM BACKWARD in front
+// of it rides on the epilogue.  The output tile is the gradient dy of that BatchNorm + ReLU's output; the lane reads the matching
+// values of the saved pre-norm tensor z (8 bytes per 16-pixel group and channel quad, the accumulator layout) and the statistics
+// rows carry sum dy' and sum dy' * xhat (dy' = dy where z*scale + shift > 0) -- what bn_bwd_reduce_kernel computes in a pass of
+// its own over dy and z (4 B/element; here 2 B/element, and dy is summed before it is rounded to bf16).
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false, bool BNR = false>
 __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a, int nco, int total_tiles, FastDiv d_nco, FastDiv d_tw, FastDiv d_th) {
     using C = Cv2Cfg<WC, KH, KW>;
     static_assert((KH == 3 && KW == 3) || (!GEN && !DST && !SPEC), "other than 3x3: the specialised kernel only");
     static_assert(!ACC || (!GEN && !DST && !SPEC), "accumulating epilogue: the specialised kernel without request waves");
     static_assert(!DYN || (!GEN && !DST && !ACC && KH == 3 && KW == 3 && (WC == 2 || SPEC)), "tile queues: 128-channel tiles or request waves");
+    static_assert(!BNR || (!GEN && !DST && !ACC && !DYN && KH == 3 && KW == 3), "BatchNorm-backward sums: the plain specialised 3x3 kernel");
     constexpr int BCO = C::BCO, RW = C::RW, NPG = C::NPG, HP = C::HP, TPP = C::TPP, NPH = C::NPH;
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -647,10 +653,38 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { s1[r] = run1[ct][r]; s2[r] = run2[ct][r]; }
                         }
+                        if constexpr (BNR) {
+                            // z in the accumulator layout: 8 bytes per lane and 16-pixel group (a pixel's four ge-lanes cover 32
+                            // contiguous bytes).  MEASURED (round 3): bringing z in as whole 128-byte lines through a wave-private LDS
+                            // transposition instead (one group ahead, scale / shift for all 16 channels in registers) costs 40 spilled
+                            // registers in the 128-channel kernel and is no faster (3.88 against 3.76 ms over the 7 launches of a step).
+                            const int chan = co_w + ct * 16 + 4 * ge;
+                            const float4 psc = *(const float4*)(a.bn_scale + chan), psh = *(const float4*)(a.bn_shift + chan);
+                            const float4 pmu = *(const float4*)(a.bn_mean + chan), pis = *(const float4*)(a.bn_invstd + chan);
+                            const float sc_[4] = {psc.x, psc.y, psc.z, psc.w}, sh_[4] = {psh.x, psh.y, psh.z, psh.w};
+                            const float mu_[4] = {pmu.x, pmu.y, pmu.z, pmu.w}, is_[4] = {pis.x, pis.y, pis.z, pis.w};
+                            const char* zb = (const char*)a.bn_z + ((pix0 + l15e) * a.bn_ldz + a.bn_zoff + chan) * 2;
+                            uint2 zq[NPG];
+#pragma unroll
+                            for (int pg = 0; pg < NPG; ++pg)
+                                zq[pg] = *(const uint2*)(zb + ((size_t)(pg >> 1) * a.Wout + (pg & 1) * 16) * a.bn_ldz * 2);
+#pragma unroll
+                            for (int pg = 0; pg < NPG; ++pg) {
+                                const float zf[4] = {__uint_as_float(zq[pg].x << 16), __uint_as_float(zq[pg].x & 0xffff0000u),
+                                                     __uint_as_float(zq[pg].y << 16), __uint_as_float(zq[pg].y & 0xffff0000u)};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float d = fmaf(zf[r], sc_[r], sh_[r]) > 0.f ? acc[ct][pg][r] : 0.f;
+                                    s1[r] += d;
+                                    s2[r] = fmaf(d, (zf[r] - mu_[r]) * is_[r], s2[r]);
+                                }
+                            }
+                        } else {
 #pragma unroll
                         for (int pg = 0; pg < NPG; ++pg)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { const float v = acc[ct][pg][r]; s1[r] += v; s2[r] = fmaf(v, v, s2[r]); }
+                        }
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float2 t;
@@ -811,7 +845,7 @@ __global__ __launch_bounds__(SPEC ? 768 : 512) void conv3x3_v2_kernel(ConvArgs a
 #endif
 }
 
-template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false>
+template <int WC, bool GEN, bool DST = false, bool SPEC = false, int KH = 3, int KW = 3, bool ACC = false, bool DYN = false, bool BNR = false>
 static int launch_conv2(ConvArgs a, hipStream_t stream) {
     using C = Cv2Cfg<WC, KH, KW>;
     constexpr int LDS = C::SMEM + (DYN ? 64 : 0);
@@ -828,7 +862,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
     const int grid = total < 256 ? total : 256;            // one persistent workgroup per CU
     UNET_CHECK((unsigned long long)total * (unsigned)(nco > a.tiles_w ? (nco > a.tiles_h ? nco : a.tiles_h) : (a.tiles_w > a.tiles_h ? a.tiles_w : a.tiles_h)) < (1ull << 32),
                "tile count too large for the index arithmetic");
-    if constexpr (!DYN && !GEN && !DST && !ACC && KH == 3 && KW == 3 && (WC == 2 || SPEC)) {
+    if constexpr (!DYN && !GEN && !DST && !ACC && !BNR && KH == 3 && KW == 3 && (WC == 2 || SPEC)) {
         // tile queues (tile_queue.h) for launches with at least three rounds of tiles (two are drawn up front)
         if (grid == 256 && a.Cin >= 64 && total >= (tileq_level() == 2 ? 256 : tileq_level() == 1 ? 3 * 256 : INT_MAX)
             && !tileq_capturing(stream)) {
@@ -837,7 +871,7 @@ static int launch_conv2(ConvArgs a, hipStream_t stream) {
             return launch_conv2<WC, GEN, DST, SPEC, KH, KW, ACC, true>(a, stream);
         }
     }
-    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC, DYN>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), LDS, stream, a, nco, total,
+    hipLaunchKernelGGL((conv3x3_v2_kernel<WC, GEN, DST, SPEC, KH, KW, ACC, DYN, BNR>), dim3((unsigned)grid), dim3(SPEC ? 768 : 512), LDS, stream, a, nco, total,
                        make_fastdiv((unsigned)nco), make_fastdiv((unsigned)a.tiles_w), make_fastdiv((unsigned)a.tiles_h));
     UNET_LAUNCH_CHECK();
     return 0;
@@ -887,6 +921,13 @@ int dispatch_conv2(const ConvArgs& a, hipStream_t s) {
     if (a.stats != nullptr && conv2_defer(a.Cin, a.Cout, a.Hout, a.Wout, a.flags, a.csplit))
         return dst_nospec ? launch_conv2<1, false, true>(a, s) : launch_conv2<1, false, true, true>(a, s);
     return launch_conv2<1, false, false, true>(a, s);
+}
+
+// 3x3 dgrad + BatchNorm-backward sums (BNR): specialised shapes only; one statistics row per 16x32 pixel tile
+bool conv2_bnred_ok(int Cin, int Cout, int Hout, int Wout) { return !conv2_gen(Cin, Cout, Hout, Wout, 0, 0) && (Cout & 63) == 0; }
+int dispatch_conv2_bnred(const ConvArgs& a, hipStream_t s) {
+    return a.Cout > 64 ? launch_conv2<2, false, false, false, 3, 3, false, false, true>(a, s)
+                       : launch_conv2<1, false, false, true, 3, 3, false, false, true>(a, s);
 }
 
 // 5x5 stride 1 on whole 16x32 tiles and whole 64-channel blocks: the LDS-DMA kernel (one stats row per pixel tile); everything

@@ -253,6 +253,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t stream) {
 // bf16 3x3 stride-1 path (conv_fwd2.hip)
 int conv2_rows(int N, int Hout, int Wout, int Cin, int Cout, int flags, int csplit);
 int dispatch_conv2(const ConvArgs& a, hipStream_t s);
+bool conv2_bnred_ok(int Cin, int Cout, int Hout, int Wout);
+int dispatch_conv2_bnred(const ConvArgs& a, hipStream_t s);
 // bf16 5x5 stride-1 path on whole tiles (conv_fwd2.hip)
 bool conv5_v2_ok(int Cin, int Cout, int Hout, int Wout, int flags, int csplit);
 int conv5_rows(int N, int Hout, int Wout);
@@ -342,4 +344,32 @@ extern "C" int unet_conv_fwd(int dtype, int kh, int kw, int stride_h, int epi,
     if (dtype == UNET_BF16 && epi == 0 && kh == 2 && kw == 1 && stride_h == 2 && convT2_dgrad_ok(a)) return convT2_dgrad(a, s);
     return dtype == UNET_BF16 ? dispatch_conv<__bf16>(kh, kw, stride_h, epi, a, s)
                               : dispatch_conv<float>(kh, kw, stride_h, epi, a, s);
+}
+
+// 3x3 stride-1 dgrad of the SECOND conv of a DoubleConv (models/unet.py:13 under autograd) with the first pass of the BatchNorm
+// backward in front of it (models/unet.py:11-12) riding on the epilogue: dy = conv3x3(dz, flipped weights) is written as usual,
+// and sum_rows [N*(H/16)*(W/32)][Cout][2] receive, per 16x32 pixel tile, sum dy' and sum dy'*xhat with dy' = dy where
+// z*scale + shift > 0 and xhat = (z - mean)*invstd -- the two sums unet_bn_relu_bwd's first pass takes from dy and z in a pass of
+// its own.  unet_bn_relu_bwd_rows consumes the rows.  bf16, whole 16x32 tiles and 64-channel blocks only: ask _ok first.
+extern "C" int unet_conv_dgrad_bnred_ok(int dtype, int H, int W, int Cin, int Cout) {
+    return dtype == UNET_BF16 && conv2_bnred_ok(Cin, Cout, H, W) ? 1 : 0;
+}
+extern "C" int unet_conv_dgrad_bnred(int dtype, const void* dz, int ldx, int xoff, const void* w_dgrad, void* dy, int ldy, int yoff,
+                                     float* sum_rows, const void* z, int ldz, int zoff,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     int N, int H, int W, int Cin, int Cout, void* stream) {
+    UNET_CHECK(unet_conv_dgrad_bnred_ok(dtype, H, W, Cin, Cout), "conv_dgrad_bnred: bf16, H %% 16 == 0, W %% 32 == 0, Cin %% 32 == 0, Cout %% 64 == 0 "
+               "only (got %dx%d, %d -> %d channels)", H, W, Cin, Cout);
+    UNET_CHECK(dz && w_dgrad && dy && sum_rows && z && scale && shift && mean && invstd, "conv_dgrad_bnred: null argument");
+    UNET_CHECK(N > 0 && ldx % 8 == 0 && xoff % 8 == 0 && ldy % 8 == 0 && yoff % 8 == 0 && ldz % 4 == 0 && zoff % 4 == 0 &&
+               xoff + Cin <= ldx && yoff + Cout <= ldy && zoff + Cout <= ldz, "conv_dgrad_bnred: bad strides / offsets");
+    UNET_CHECK((size_t)H * W * ldx < (1ull << 31) && (size_t)9 * Cout * Cin * 2 < (1ull << 31), "conv_dgrad_bnred: tensor too large");
+    ConvArgs a;
+    a.x = dz; a.w = w_dgrad; a.bias = nullptr; a.y = dy; a.stats = sum_rows;
+    a.N = N; a.Hin = H; a.Win = W; a.Cin = Cin; a.ldx = ldx; a.xoff = xoff;
+    a.Hout = H; a.Wout = W; a.Cout = Cout; a.ldy = ldy; a.yoff = yoff;
+    a.pad_h = 1; a.pad_w = 1; a.tiles_h = H / 16; a.tiles_w = W / 32;
+    a.y2 = nullptr; a.ldy2 = 0; a.yoff2 = 0; a.csplit = 0; a.flags = 0; a.tq = nullptr;
+    a.bn_z = z; a.bn_ldz = ldz; a.bn_zoff = zoff; a.bn_scale = scale; a.bn_shift = shift; a.bn_mean = mean; a.bn_invstd = invstd;
+    return dispatch_conv2_bnred(a, (hipStream_t)stream);
 }

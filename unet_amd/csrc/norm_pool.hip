@@ -690,7 +690,7 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
                             void* dz, int ldo, int ooff,
                             const float* scale, const float* shift, const float* mean, const float* invstd,
                             float* dgamma, float* dbeta, float* dbias, float* c1c2_ws, double* acc_ws,
-                            long long M, int C, void* stream) {
+                            long long M, int C, void* stream, const float* sum_rows = nullptr, int nrows = 0) {
     if (chan_check(dtype, C, "bn_relu_bwd")) return -1;
     UNET_CHECK(scale && shift && mean && invstd, "bn_relu_bwd: scale / shift / mean / invstd must not be NULL");
     UNET_CHECK(dy && z && dz && dgamma && dbeta && acc_ws, "bn_relu_bwd: null argument");
@@ -711,7 +711,11 @@ static int bn_relu_bwd_impl(PoolSrc ps, int dtype, int relu, const void* dy, int
     double* dbacc = dbias ? acc_ws + 2 * C : nullptr;
 #define LAUNCH_R(T, R) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, R, POOL>), dim3(grid), dim3(256), lds1, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, scale, shift, mean, invstd, M, C, acc_ws)
 #define LAUNCH_A(T, R) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, R, POOL>), dim3(grid), dim3(256), lds2, s, ps, (const T*)dy, ldd, doff, (const T*)z, ldz, zoff, (T*)dz, ldo, ooff, scale, shift, mean, invstd, acc_ws, (double)M, frozen, dgamma, dbeta, M, C, dbacc, dbias, (unsigned*)(acc_ws + 3 * C))
-    if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
+    if (sum_rows != nullptr) {
+        // the first pass's sums arrive as per-tile rows from the producing dgrad's epilogue (unet_conv_dgrad_bnred)
+        int S = (nrows + 63) / 64; if (S > 64) S = 64; if (S < 1) S = 1;
+        hipLaunchKernelGGL(bn_stats_reduce_kernel, dim3((C + 31) / 32, S), dim3(256), 0, s, sum_rows, nrows, C, acc_ws);
+    } else if (dtype == UNET_BF16) { if (relu) LAUNCH_R(__bf16, true); else LAUNCH_R(__bf16, false); }
     else { if (relu) LAUNCH_R(float, true); else LAUNCH_R(float, false); }
     UNET_LAUNCH_CHECK();
     if (dtype == UNET_BF16) { if (relu) LAUNCH_A(__bf16, true); else LAUNCH_A(__bf16, false); }
@@ -730,6 +734,19 @@ extern "C" int unet_bn_relu_bwd(int dtype, int relu, const void* dy, int ldd, in
                                 long long M, int C, void* stream) {
     return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
                                    scale, shift, mean, invstd, dgamma, dbeta, dbias, c1c2_ws, acc_ws, M, C, stream);
+}
+
+// unet_bn_relu_bwd whose first pass has already run inside the dgrad that produced dy (unet_conv_dgrad_bnred): sum_rows
+// [nrows][C][2] hold per-tile (sum dy', sum dy'*xhat); they are added up in fp64 and the second pass runs as usual.
+extern "C" int unet_bn_relu_bwd_rows(int dtype, int relu, const void* dy, int ldd, int doff, const void* z, int ldz, int zoff,
+                                     void* dz, int ldo, int ooff,
+                                     const float* scale, const float* shift, const float* mean, const float* invstd,
+                                     float* dgamma, float* dbeta, float* dbias /* nullable */,
+                                     const float* sum_rows, int nrows, double* acc_ws /* 3*C + 2 doubles */,
+                                     long long M, int C, void* stream) {
+    UNET_CHECK(sum_rows != nullptr && nrows > 0, "bn_relu_bwd_rows: no rows");
+    return bn_relu_bwd_impl<false>(PoolSrc{nullptr, nullptr, 0, 0}, dtype, relu, dy, ldd, doff, z, ldz, zoff, dz, ldo, ooff,
+                                   scale, shift, mean, invstd, dgamma, dbeta, dbias, nullptr, acc_ws, M, C, stream, sum_rows, nrows);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -53,6 +53,11 @@ class UNetEngine:
         # Batch statistics of the fused first layer from the image's 3x3 patch moments (z is linear in the patch): 73 us instead
         # of 257 us at 32x512x512, and the backward reuses the moments.  UNET_AMD_FIRST_STATS_CONV=1: the statistics-only conv pass.
         self.first_stats_moments = os.environ.get("UNET_AMD_FIRST_STATS_CONV", "0") != "1"
+        # First pass of the BatchNorm backward of a DoubleConv's FIRST norm inside the dgrad of its second conv (ops.conv_dgrad_bnred).
+        # Correct and tested (tests/test_gpu_realwidth.py), but MEASURED NOT TO PAY (round 3, same box, per step): the eight
+        # reduction passes it removes cost 1.05 ms, the z reads + sums + per-tile cross-wave reduction it adds to the epilogues of
+        # eight dgrad launches cost 1.2 ms (the epilogue is the one part of those kernels no MFMA overlaps).  Off by default.
+        self.bn_reduce_in_dgrad = os.environ.get("UNET_AMD_BN_REDUCE_IN_DGRAD", "0") == "1"
         self.keep_saved = False      # tests: leave the last forward's saved activations in self.last_saved
         self.last_saved = None
         # Weight gradients on a side stream (wgrad_async).  Measured: -0.4...-0.7 ms per step (1-1.5 %), all of it tail
@@ -342,7 +347,13 @@ class UNetEngine:
         w2 = P[r2.wname]
         grads[r2.wname] = self.wgrad_async(dev, lambda w_: ops.conv_wgrad(dz2, r2.xin, 3, 3, w_)[0].view_as(w2), [dz2.buf, r2.xin.buf])
         dy1 = ops.dense(z2.N, z2.H, z2.W, w2.shape[1], dt, dev)
-        ops.conv_fwd(dz2, self.packed(r2.wname, w2, 1, dt), None, dy1, 3, 3, w2.shape[0], w2.shape[1])
+        # the first pass of the NEXT BatchNorm backward (sum dy', sum dy'*xhat over dy1 and z1) rides on this dgrad's epilogue
+        # where the fused kernel takes the shape (bf16, whole tiles): dy1 is then read once, by the apply pass, not twice
+        rows1 = None
+        if self.bn_reduce_in_dgrad and not getattr(r1, "fused_first", False) and r1.z is not None and type(self) is UNetEngine:
+            rows1 = ops.conv_dgrad_bnred(dz2, self.packed(r2.wname, w2, 1, dt), dy1, r1.z, r1.st)
+        if rows1 is None:
+            ops.conv_fwd(dz2, self.packed(r2.wname, w2, 1, dt), None, dy1, 3, 3, w2.shape[0], w2.shape[1])
         del dz2
         # first conv
         w1 = P[r1.wname]
@@ -355,7 +366,7 @@ class UNetEngine:
             return None
         z1 = r1.z
         dz1 = ops.dense(z1.N, z1.H, z1.W, z1.C, dt, dev)
-        dg, db_, dbias = ops.bn_relu_bwd(dy1, z1, dz1, r1.st, ws)
+        dg, db_, dbias = ops.bn_relu_bwd(dy1, z1, dz1, r1.st, ws, sum_rows=rows1)
         grads[r1.bnp + ".weight"], grads[r1.bnp + ".bias"], grads[r1.bname] = dg, db_, dbias
         del dy1
         if r1.first:

@@ -568,8 +568,27 @@ def affine_act_pool(z: Act, y: Act, st: BNState, relu=True):
     return pooled, code
 
 
-def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True, want_dbias=True):
-    """-> (dgamma, dbeta, dbias|None); dz is written."""
+def conv_dgrad_bnred(dz: Act, w_dgrad: torch.Tensor, dy: Act, z: Act, st: "BNState") -> Optional[torch.Tensor]:
+    """dy = 3x3 dgrad of dz (w_dgrad = pack_weights(w, 1, dt)) AND, from the same kernel's epilogue, the per-tile rows
+    (sum dy', sum dy'*xhat) of the BatchNorm + ReLU whose pre-norm tensor is z and whose output gradient dy is: the first pass of
+    bn_relu_bwd without a pass of its own (hand the rows to bn_relu_bwd(sum_rows=...)).  Returns None -- nothing launched --
+    when the shape is not one the fused kernel takes (bf16, whole 16x32 tiles, 64-channel blocks): use conv_fwd then."""
+    dz.check(); dy.check(); z.check()
+    N, H, W, Cin, Cout = dz.N, dz.H, dz.W, dz.C, dy.C
+    if (dy.N, dy.H, dy.W) != (N, H, W) or (z.N, z.H, z.W, z.C) != (N, H, W, Cout) or not (dz.dt == dy.dt == z.dt):
+        raise UNetHipError("conv_dgrad_bnred: shape mismatch")
+    if st.mean is None or st.invstd is None or not lib().unet_conv_dgrad_bnred_ok(dz.dt, H, W, Cin, Cout):
+        return None
+    rows = torch.empty((N * (H // 16) * (W // 32), Cout, 2), dtype=torch.float32, device=dz.buf.device)
+    check(lib().unet_conv_dgrad_bnred(dz.dt, _p(dz.buf), dz.ld, dz.off, _p(w_dgrad), _p(dy.buf), dy.ld, dy.off, _p(rows),
+                                      _p(z.buf), z.ld, z.off, _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                      N, H, W, Cin, Cout, _stream()), "conv_dgrad_bnred")
+    return rows
+
+
+def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True, want_dbias=True,
+                sum_rows: Optional[torch.Tensor] = None):
+    """-> (dgamma, dbeta, dbias|None); dz is written.  sum_rows: the first pass's sums as per-tile rows from conv_dgrad_bnred."""
     dy.check(); z.check(); dz.check()
     C = z.C
     if dy.C != C or dz.C != C or dy.M != z.M or dz.M != z.M or dy.dt != z.dt or dz.dt != z.dt:
@@ -578,6 +597,15 @@ def bn_relu_bwd(dy: Act, z: Act, dz: Act, st: BNState, ws: Workspace, relu=True,
         raise UNetHipError("bn_relu_bwd: workspace too small")
     g = torch.empty((3, C), dtype=torch.float32, device=z.buf.device)
     acc = ws.take_zeroed(3 * C + 2)
+    if sum_rows is not None:
+        if not relu or sum_rows.dtype != torch.float32 or not sum_rows.is_contiguous() or tuple(sum_rows.shape[1:]) != (C, 2):
+            raise UNetHipError("bn_relu_bwd: sum_rows must be contiguous fp32 [nrows, C, 2] of a BatchNorm + ReLU")
+        check(lib().unet_bn_relu_bwd_rows(z.dt, _bn_bwd_flags(st, relu) | (4 if acc is not None else 0), _p(dy.buf), dy.ld, dy.off,
+                                          _p(z.buf), z.ld, z.off, _p(dz.buf), dz.ld, dz.off,
+                                          _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
+                                          _p(g[0]), _p(g[1]), _p(g[2]) if want_dbias else None, _p(sum_rows), sum_rows.shape[0],
+                                          _p(acc if acc is not None else ws.acc), z.M, C, _stream()), "bn_relu_bwd_rows")
+        return g[0], g[1], (g[2] if want_dbias else None)
     check(lib().unet_bn_relu_bwd(z.dt, _bn_bwd_flags(st, relu) | (4 if acc is not None else 0), _p(dy.buf), dy.ld, dy.off,
                                  _p(z.buf), z.ld, z.off,
                                  _p(dz.buf), dz.ld, dz.off, _p(st.scale), _p(st.shift), _p(st.mean), _p(st.invstd),
