@@ -170,8 +170,14 @@ def main():
     if use_dist:
         # HIP's default of 4 hardware queues per process lets torch's RCCL stream land on the compute stream's queue, where
         # the all-reduces run in order with the kernels instead of under them; must be set before the
-        # first HIP call of the process
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # first HIP call of the process.  The pool's boxes EXPORT the default (4), so a setdefault would do nothing: raise
+        # anything below 8 to 8, leave a larger setting of the operator's alone
+        try:
+            hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            hwq = 4
+        if hwq < 8:
+            os.environ["GPU_MAX_HW_QUEUES"] = "8"
     if args.force_dist:
         os.environ["UNET_AMD_DP_FORCE_COLLECTIVES"] = "1"      # the one-rank rehearsal still launches the RCCL collectives
     if use_dist:

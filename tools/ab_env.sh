@@ -1,10 +1,17 @@
 #!/bin/bash
-# same-box A/B of the conv microbenchmark between two settings of one environment variable:
-#   tools/ab_env.sh VAR valueA valueB layer...
-VAR=$1; A=$2; B=$3; shift 3
-for l in "$@"; do
-  for v in $A $B; do
-    echo -n "$VAR=$v "
-    env $VAR=$v timeout -k 10 200 python -u tools/conv_microbench.py --iters 20 --only $l 2>&1 | grep "\->" | head -1 || exit 1
+# Same-box A/B of the bench step over values of ONE environment variable, interleaved, ROUNDS times:
+#   bash tools/ab_env.sh VAR "v1 v2 v3" [ROUNDS] [STEPS]
+# prints "VAR=v ms_per_step" per run (gpurun_out/ab_env.log keeps them)
+set -e
+VAR=$1; VALS=$2; ROUNDS=${3:-2}; STEPS=${4:-60}
+R=${GRAFT_REPO_ROOT:-.}
+cd $R
+mkdir -p gpurun_out
+: > gpurun_out/ab_env.log
+for r in $(seq 1 $ROUNDS); do
+  for v in $VALS; do
+    export $VAR=$v
+    timeout -k 10 200 python3 -u bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-conv-timer > gpurun_out/ab_env_one.json 2> gpurun_out/ab_env_one.err
+    python3 -c "import json,sys; d=json.loads(open('gpurun_out/ab_env_one.json').read().strip().splitlines()[-1]); print('$VAR=$v', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a gpurun_out/ab_env.log
   done
 done
