@@ -18,7 +18,8 @@ def dev():
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("shape", [(2, 20, 36, 16), (1, 33, 31, 64), (3, 16, 32, 24), (2, 64, 64, 64)])
+# the last shape has more tiles (640) than the LDS-ring backward kernel has workgroups (512): its request stream crosses tile boundaries
+@pytest.mark.parametrize("shape", [(2, 20, 36, 16), (1, 33, 31, 64), (3, 16, 32, 24), (2, 64, 64, 64), (20, 128, 512, 64)])
 def test_first_layer_fused_vs_torch(dev, dt, shape):
     from unet_amd import ops
     N, H, W, Cout = shape
@@ -64,7 +65,11 @@ def test_first_layer_fused_vs_torch(dev, dt, shape):
     # handing the forward's moments over gives the same numbers as letting the backward compute them (fp64 atomics: to rounding)
     dgm, dbm, _, dwm = ops.first_bn_relu_bwd(to_act(dyv, dt, dev), xh, wd, bd, st, ws, moments=mom)
     assert torch.equal(dgm, dg) and torch.equal(dbm, db_) and float((dwm - dw).abs().max()) <= 1e-6 * float(dw.abs().max())
-    if dt == 0:
+    if dt == 0 and N * H * W < 500_000:
+        # (the 1.3 M-pixel shape: 84 M pre-activations, of which a handful sit within an fp32 rounding of zero and take the
+        # other side in torch's conv, whose sum runs in another order; one such pixel moves a channel's dgamma by |dy * xhat|,
+        # far above 2e-5 of the sum.  That shape is pinned by the comparison with the separate kernels below, which make the
+        # same decisions bit for bit.)
         # bf16: the batch statistics come from the fp32 conv output while the normalised tensor is its bf16 rounding, so a
         # few ReLU decisions differ from torch's and each moves a per-channel sum by ~1/sqrt(n); the bf16 backward is
         # pinned by the comparison with the separate kernels below (and by the whole-model tests)
@@ -89,7 +94,18 @@ def test_first_layer_fused_vs_torch(dev, dt, shape):
     # by that rounding noise, 2^-9 per element averaged over the pixels (fp32: no such roundings, same 1e-4 bound)
     for a_, b_, what in ((dg, dg2, "dgamma"), (db_, db2, "dbeta")):
         assert float((a_ - b_).abs().max()) <= 1e-4 * float(b_.abs().max()), what
-    assert float((dw - dw2).abs().max()) <= (1e-4 if dt == 0 else 2 ** -8) * float(dw2.abs().max()), "dW"
+    e_dw = float((dw - dw2).abs().max()) / float(dw2.abs().max())
+    if dt == 1 and N * H * W >= 500_000:
+        # At 1.3 M pixels the separate kernels' bf16 dz is the worse of the two: c1 = S1/n and xhat*c2 are ~1e-3 against
+        # |dy'| ~ 1 with dy' ON the bf16 grid, so rounding dz = scale*(dy' - c1 - xhat*c2) back to bf16 returns scale*dy' and
+        # the mean-subtraction is lost (sum of the stored dz: 1.2e3 instead of ~0), which moves that path's dW by 10 %.  The
+        # fused pass never rounds dz: it is the one compared with torch here (measured 6e-4 / 9e-5).
+        assert e_dw > 2 ** -8, "the separate kernels were expected to be the less accurate path at this size"
+        for got, ref, what in ((dw, w.grad, "dW"), (dg, gamma.grad, "dgamma"), (db_, beta.grad, "dbeta")):
+            e = float((got.cpu() - ref).abs().max()) / float(ref.abs().max())
+            assert e <= 5e-3, f"{what}: fused one-pass vs torch {e:.3e}"
+    else:
+        assert e_dw <= (1e-4 if dt == 0 else 2 ** -8), f"dW: fused one-pass vs separate kernels {e_dw:.3e}"
 
 
 @pytest.mark.parametrize("dt", [0, 1])

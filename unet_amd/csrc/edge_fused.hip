@@ -18,6 +18,7 @@
 // dy, dz0) is rounded to T here at the same point (round_to<T>), so the two paths agree to the last bit except for the
 // order of fp64 atomic adds.
 #include "bn_shared.h"
+#include "lds_dma.h"
 #include <cstdlib>
 
 // =================================================================================================
@@ -191,6 +192,310 @@ __global__ __launch_bounds__(256) void first1_bn_bwd_kernel(const T* __restrict_
             block_reduce_to_acc<EPV>(m, pt, EPV, Cout, wacc + t, 9);
         }
     }
+}
+
+// One dword per lane to LDS through a buffer descriptor (lane-linear, 256 bytes per wave instruction); a lane whose voff is
+// beyond num_records writes ZERO -- the conv's zero padding for the 1-channel image.
+__device__ __forceinline__ void lds_dma4_buf(i32x4_t rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+// The single-pass backward (PASS 3 of first1_bn_bwd_kernel: S1, S2 and A[co][tap] = sum dy' * x[p + tap]) with its operands
+// streamed through a wave-private LDS RING by LDS-DMA.
+//
+// Why: the arithmetic needs ~240 registers (72 weights + 72 weight-gradient partials per lane), i.e. two waves per SIMD, and a
+// register prefetch of the gradient one row ahead left ONE 1-KiB request per wave in flight: a row took one HBM latency
+// (~2 500 cycles against ~1 000 of arithmetic for a SIMD's two waves) and the pass ran at 1.7 TB/s.  The image rows cannot
+// simply be prefetched deeper either -- vmcnt returns in order, so a shallow x load queues behind every older gradient load.
+// Here nothing on the loop's path is a register load: each step's gradient row (64 lanes x 16 B) and image row (the wave's
+// pixel columns + 2, one dword per lane, borders zero-filled by the descriptor) are DMA'd FR_D steps ahead into the wave's
+// ring, counted with vmcnt by hand, and read back with ds_read when their step comes.  No workgroup barrier in the loop: every
+// wave owns its columns and its ring.
+//
+// Stream: a tile is FR_ROWS image rows of the workgroup's PL columns; it takes rows + 2 steps, step j carrying image row
+// h0 - 1 + j and gradient row h0 + j - 2 (steps 0 and 1 re-request row h0: 3 % of the gradient traffic), so that the 3-row
+// window is complete when the gradient row arrives and a tile boundary is just another step.
+#ifndef FR_DEPTH
+#define FR_DEPTH 8
+#endif
+constexpr int FR_D = FR_DEPTH;                 // ring depth (steps in flight per wave)
+constexpr int FR_SLOT = 1024 + 256;            // bytes per step and wave: gradient row + image row
+constexpr int FR_ROWS = 64;                    // image rows per tile
+static inline size_t first_ring_lds_bytes() { return (size_t)4 * FR_D * FR_SLOT; }
+
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void first1_bn_bwd_ring_kernel(const T* __restrict__ dy, int ldd, int doff,
+                                                                 const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 int N, int H, int W, int Cout, unsigned xbytes,
+                                                                 double* __restrict__ acc, double* __restrict__ wacc) {
+    constexpr int EPV = TT<T>::EPV;
+    extern __shared__ float red_lds[];
+    ChanMap m; m.init<T>(Cout);
+    float part[2 * EPV];
+#pragma unroll
+    for (int i = 0; i < 2 * EPV; ++i) part[i] = 0.f;
+    float pw[9][EPV];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) pw[t][e] = 0.f;
+    float wr[9][EPV], b[EPV], sc[EPV], sh[EPV], mu[EPV], is[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        const int c = (m.active ? m.cg : 0) * EPV + e;
+        b[e] = bias != nullptr ? bias[c] : 0.f;
+        sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; is[e] = invstd[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t][e] = w[c * 9 + t];
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pb = (wave * 64) / m.G;                              // first pixel column (of the tile's PL) this wave owns
+    const int npx = min((wave * 64 + 63) / m.G, m.PL - 1) - pb + 1; // and how many: the image row needs npx + 2 dwords
+    const int mp = m.pl - pb;                                      // this lane's pixel inside the wave's run
+    const int tiles_w = (W + m.PL - 1) / m.PL, tiles_h = (H + FR_ROWS - 1) / FR_ROWS;
+    const int per_img = tiles_w * tiles_h;
+    const int total = per_img * N;
+    const i32x4_t xrsrc = make_rsrc(x, xbytes);
+    const unsigned ring0 = lds_addr(red_lds) + (unsigned)wave * (FR_D * FR_SLOT);
+    const char* ringp = (const char*)red_lds + wave * (FR_D * FR_SLOT);
+    const long long rowbytes = (long long)W * ldd * (long long)sizeof(T);
+
+    // ---- request cursor: the (tile, step) sequence below, FR_D steps ahead.  Plain locals and macros on purpose: state captured
+    // by a lambda stays in scratch memory next to the asm statements' "memory" clobbers, and scratch loads are vmcnt traffic ----
+    int ptile = blockIdx.x, pj = 0, pslots = 0, phh = 0;
+    const char* pdy = (const char*)(dy + doff);                    // always a valid address (dummy requests once the stream is dry)
+    unsigned pxoff = 0;
+    bool pxcol = false;
+// timing-only experiment builds (results wrong by construction): -DFR_X_NODMA drops both requests, -DFR_X_NOXDMA the image
+// row's, -DFR_X_NOCOMP the arithmetic
+#if defined(FR_X_NODMA)
+#define FR_DMA_DY(a, b) asm volatile("" :: "v"(a), "s"(b))
+#define FR_DMA_X(r, o, d) asm volatile("" :: "s"(r), "v"(o), "s"(d))
+#define FR_VMCNT 0
+#elif defined(FR_X_NOXDMA)
+#define FR_DMA_DY(a, b) lds_dma16(a, b)
+#define FR_DMA_X(r, o, d) asm volatile("" :: "s"(r), "v"(o), "s"(d))
+#define FR_VMCNT (FR_D - 1)
+#else
+#define FR_DMA_DY(a, b) lds_dma16(a, b)
+#define FR_DMA_X(r, o, d) lds_dma4_buf(r, o, d)
+#define FR_VMCNT (2 * (FR_D - 1))
+#endif
+#define FR_OPEN()                                                                                                   \
+    do {                                                                                                            \
+        if (ptile >= total) { pslots = 0; break; }                                                                  \
+        const int n_ = ptile / per_img, tt_ = ptile - n_ * per_img;                                                 \
+        const int th_ = tt_ / tiles_w, tw_ = tt_ - th_ * tiles_w;                                                   \
+        const int h0_ = th_ * FR_ROWS, w0_ = tw_ * m.PL;                                                            \
+        pslots = min(h0_ + FR_ROWS, H) - h0_ + 2;                                                                   \
+        pj = 0;                                                                                                     \
+        phh = h0_ - 1;                                                                                              \
+        const int wq_ = min(w0_ + (m.active ? m.pl : 0), W - 1);   /* lanes without a column request a valid one */ \
+        pdy = (const char*)(dy + (((long long)n_ * H + h0_) * W + wq_) * ldd + doff + (m.active ? m.cg : 0) * EPV); \
+        const int col_ = w0_ + pb - 1 + lane;                                                                       \
+        pxcol = lane < npx + 2 && col_ >= 0 && col_ < W;                                                            \
+        pxoff = (unsigned)((((long long)n_ * H + (h0_ - 1)) * W + col_) * 4);                                       \
+    } while (0)
+#define FR_REQUEST(slot_)                                                                                           \
+    do {                                                                                                            \
+        const unsigned dst_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring0 + (slot_) * FR_SLOT));           \
+        FR_DMA_DY(pdy, dst_);                                                                                       \
+        FR_DMA_X(xrsrc, (pxcol && (unsigned)phh < (unsigned)H) ? pxoff : LDS_DMA_OOB, dst_ + 1024);                 \
+        if (pslots != 0) {                                                                                          \
+            ++pj; ++phh; pxoff += (unsigned)W * 4u;                                                                 \
+            if (pj > 2 && pj < pslots) pdy += rowbytes;            /* step j carries gradient row h0 + max(j - 2, 0) */ \
+            if (pj == pslots) { ptile += gridDim.x; FR_OPEN(); }                                                    \
+        }                                                                                                           \
+    } while (0)
+    FR_OPEN();
+#pragma unroll 1
+    for (int k = 0; k < FR_D; ++k) FR_REQUEST((unsigned)k);
+
+    unsigned cnt = 0;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int tt = tile % per_img;
+        const int th = tt / tiles_w, tw = tt - th * tiles_w;
+        const int h0 = th * FR_ROWS;
+        const int slots = min(h0 + FR_ROWS, H) - h0 + 2;
+        const bool mine = m.active && tw * m.PL + m.pl < W;
+        float ra[3] = {0.f, 0.f, 0.f}, rb[3] = {0.f, 0.f, 0.f}, rc[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < slots; ++j) {
+            // the oldest step's two requests have landed once at most 2 * (FR_D - 1) are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FR_VMCNT) : "memory");
+            const unsigned slot = cnt & (FR_D - 1);
+            const char* sp = ringp + slot * FR_SLOT;
+            const uint4 gq = *(const uint4*)(sp + lane * 16);
+            const float x0 = *(const float*)(sp + 1024 + mp * 4);
+            const float x1 = *(const float*)(sp + 1024 + mp * 4 + 4);
+            const float x2 = *(const float*)(sp + 1024 + mp * 4 + 8);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in registers before the slot is requested again
+            FR_REQUEST(slot);
+            ++cnt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+            rc[0] = x0; rc[1] = x1; rc[2] = x2;
+            if (j < 2 || !mine) continue;
+            float fd[EPV];
+            Vec16<T>::unpack(gq, fd);
+#ifdef FR_X_NOCOMP
+            part[0] += fd[0] + rc[0] + ra[1] + rb[2];
+            continue;
+#endif
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float v = b[e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    v = fmaf(ra[k], wr[k][e], v);
+                    v = fmaf(rb[k], wr[3 + k][e], v);
+                    v = fmaf(rc[k], wr[6 + k][e], v);
+                }
+                const float z = round_to<T>(v);
+                const float d = (!RELU || fmaf(z, sc[e], sh[e]) > 0.f) ? fd[e] : 0.f;
+                const float xh = (z - mu[e]) * is[e];
+                part[e] += d;
+                part[EPV + e] += d * xh;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    pw[k][e] = fmaf(d, ra[k], pw[k][e]);
+                    pw[3 + k][e] = fmaf(d, rb[k], pw[3 + k][e]);
+                    pw[6 + k][e] = fmaf(d, rc[k], pw[6 + k][e]);
+                }
+            }
+        }
+    }
+    // the dummy requests of the last FR_D steps are still landing in the ring, and the reductions reuse its LDS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    block_reduce_to_acc<2 * EPV>(m, part, EPV, Cout, acc, 2);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        float pt[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) pt[e] = pw[t][e];
+        block_reduce_to_acc<EPV>(m, pt, EPV, Cout, wacc + t, 9);
+    }
+#undef FR_OPEN
+#undef FR_REQUEST
+#undef FR_DMA_DY
+#undef FR_DMA_X
+#undef FR_VMCNT
+}
+
+// The fused forward pass (first1_bn_act_kernel's arithmetic) on the same ring: only the image row travels through LDS, the output
+// leaves by ordinary 16-byte stores.  What this buys is on the STORE side: vmcnt counts stores too and returns in order, so
+// the register-prefetch form, which waits for the next image row every step, also waited for the previous step's store to be
+// acknowledged -- one 1-KiB store in flight per wave, 3.3 TB/s.  Here the wait is counted by hand: the row of step s is older than
+// the FA_D - 1 requests issued after it whatever the stores do (steps 0 and 1 of a tile and waves without columns store nothing),
+// so vmcnt(FA_D - 1) is always sufficient, and in the steady state it leaves about FA_D / 2 stores per wave in flight.
+constexpr int FA_D = 16;
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void first1_bn_act_ring_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 T* __restrict__ y, int ldy, int yoff, int N, int H, int W, int Cout,
+                                                                 unsigned xbytes) {
+    constexpr int EPV = TT<T>::EPV;
+    constexpr int XSLOT = 256;
+    extern __shared__ float red_lds[];
+    ChanMap m; m.init<T>(Cout);
+    float wr[9][EPV], b[EPV], sc[EPV], sh[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        const int c = (m.active ? m.cg : 0) * EPV + e;
+        b[e] = bias != nullptr ? bias[c] : 0.f;
+        sc[e] = scale[c]; sh[e] = shift[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[t][e] = w[c * 9 + t];
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pb = (wave * 64) / m.G;
+    const int npx = min((wave * 64 + 63) / m.G, m.PL - 1) - pb + 1;
+    const int mp = m.pl - pb;
+    const int tiles_w = (W + m.PL - 1) / m.PL, tiles_h = (H + FR_ROWS - 1) / FR_ROWS;
+    const int per_img = tiles_w * tiles_h;
+    const int total = per_img * N;
+    const i32x4_t xrsrc = make_rsrc(x, xbytes);
+    const unsigned ring0 = lds_addr(red_lds) + (unsigned)wave * (FA_D * XSLOT);
+    const char* ringp = (const char*)red_lds + wave * (FA_D * XSLOT);
+
+    int ptile = blockIdx.x, pj = 0, pslots = 0, phh = 0;
+    unsigned pxoff = 0;
+    bool pxcol = false;
+#define FA_OPEN()                                                                                                   \
+    do {                                                                                                            \
+        if (ptile >= total) { pslots = 0; break; }                                                                  \
+        const int n_ = ptile / per_img, tt_ = ptile - n_ * per_img;                                                 \
+        const int th_ = tt_ / tiles_w, tw_ = tt_ - th_ * tiles_w;                                                   \
+        const int h0_ = th_ * FR_ROWS, w0_ = tw_ * m.PL;                                                            \
+        pslots = min(h0_ + FR_ROWS, H) - h0_ + 2;                                                                   \
+        pj = 0;                                                                                                     \
+        phh = h0_ - 1;                                                                                              \
+        const int col_ = w0_ + pb - 1 + lane;                                                                       \
+        pxcol = lane < npx + 2 && col_ >= 0 && col_ < W;                                                            \
+        pxoff = (unsigned)((((long long)n_ * H + (h0_ - 1)) * W + col_) * 4);                                       \
+    } while (0)
+#define FA_REQUEST(slot_)                                                                                           \
+    do {                                                                                                            \
+        const unsigned dst_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(ring0 + (slot_) * XSLOT));             \
+        lds_dma4_buf(xrsrc, (pslots != 0 && pxcol && (unsigned)phh < (unsigned)H) ? pxoff : LDS_DMA_OOB, dst_);     \
+        if (pslots != 0) {                                                                                          \
+            ++pj; ++phh; pxoff += (unsigned)W * 4u;                                                                 \
+            if (pj == pslots) { ptile += gridDim.x; FA_OPEN(); }                                                    \
+        }                                                                                                           \
+    } while (0)
+    FA_OPEN();
+#pragma unroll 1
+    for (int k = 0; k < FA_D; ++k) FA_REQUEST((unsigned)k);
+
+    unsigned cnt = 0;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / per_img, tt = tile - n * per_img;
+        const int th = tt / tiles_w, tw = tt - th * tiles_w;
+        const int h0 = th * FR_ROWS;
+        const int slots = min(h0 + FR_ROWS, H) - h0 + 2;
+        const int wq = tw * m.PL + m.pl;
+        const bool mine = m.active && wq < W;
+        T* yp = y + (((long long)n * H + h0) * W + (mine ? wq : 0)) * ldy + yoff + (m.active ? m.cg : 0) * EPV;
+        float ra[3] = {0.f, 0.f, 0.f}, rb[3] = {0.f, 0.f, 0.f}, rc[3] = {0.f, 0.f, 0.f};
+        for (int j = 0; j < slots; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(FA_D - 1) : "memory");
+            const unsigned slot = cnt & (FA_D - 1);
+            const char* sp = ringp + slot * XSLOT;
+            const float x0 = *(const float*)(sp + mp * 4);
+            const float x1 = *(const float*)(sp + mp * 4 + 4);
+            const float x2 = *(const float*)(sp + mp * 4 + 8);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            FA_REQUEST(slot);
+            ++cnt;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { ra[k] = rb[k]; rb[k] = rc[k]; }
+            rc[0] = x0; rc[1] = x1; rc[2] = x2;
+            float o[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float v = b[e];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    v = fmaf(ra[k], wr[k][e], v);
+                    v = fmaf(rb[k], wr[3 + k][e], v);
+                    v = fmaf(rc[k], wr[6 + k][e], v);
+                }
+                v = fmaf(round_to<T>(v), sc[e], sh[e]);
+                o[e] = RELU ? fmaxf(v, 0.f) : v;
+            }
+            if (j >= 2 && mine) *(uint4*)(yp + (long long)(j - 2) * W * ldy) = Vec16<T>::pack(o);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef FA_OPEN
+#undef FA_REQUEST
 }
 
 static __global__ void first1_store_kernel(const double* __restrict__ dbacc, const double* __restrict__ wacc, int C,
@@ -529,6 +834,21 @@ extern "C" int unet_first_bn_act(int dtype, int relu, const float* x, const floa
     UNET_CHECK(x && w && scale && shift && y, "first_bn_act: null argument");
     UNET_CHECK(N > 0 && H > 0 && W > 0 && ldy % 8 == 0 && yoff % 8 == 0 && yoff + Cout <= ldy, "first_bn_act: bad shape");
     hipStream_t s = (hipStream_t)stream;
+    // the image rows through the LDS ring (first1_bn_act_ring_kernel) under the same conditions as the backward;
+    // UNET_AMD_FIRST_FWD_RING=0: the register-prefetch kernel (A/B runs)
+    static const bool ring_off = [] { const char* e = getenv("UNET_AMD_FIRST_FWD_RING"); return e && atoi(e) == 0; }();
+    const int G = Cout / (dtype == UNET_BF16 ? 8 : 4);
+    const unsigned long long xbytes = (unsigned long long)N * H * W * 4ull;
+    const long long rt = (long long)N * ((H + FR_ROWS - 1) / FR_ROWS) * ((W + 256 / G - 1) / (256 / G));
+    if (!ring_off && G >= 2 && xbytes < 0xFFFFFF00ull && rt < (1ll << 30)) {
+        const int rgrid = (int)(rt < 1024 ? rt : 1024);            // four workgroups per CU
+#define LA(T, R) hipLaunchKernelGGL((first1_bn_act_ring_kernel<T, R>), dim3(rgrid), dim3(256), (size_t)4 * FA_D * 256, s, x, w, bias, scale, shift, (T*)y, ldy, yoff, N, H, W, Cout, (unsigned)xbytes)
+        if (dtype == UNET_BF16) { if (relu & 1) LA(__bf16, true); else LA(__bf16, false); }
+        else { if (relu & 1) LA(float, true); else LA(float, false); }
+#undef LA
+        UNET_LAUNCH_CHECK();
+        return 0;
+    }
     const dim3 grid(first_gx2(dtype, N, H, W, Cout), N);
 #define LA(T, R) hipLaunchKernelGGL((first1_bn_act_kernel<T, R>), grid, dim3(256), 0, s, x, w, bias, scale, shift, (T*)y, ldy, yoff, H, W, Cout)
     if (dtype == UNET_BF16) { if (relu & 1) LA(__bf16, true); else LA(__bf16, false); }
@@ -588,7 +908,21 @@ extern "C" int unet_first_bn_relu_bwd(int dtype, int relu, const void* dy, int l
     if (!two_pass) {
         if (moments == nullptr) { if (int rc = launch_first_moments(x, N, H, W, mom, s)) return rc; }
         const double* mom_use = moments != nullptr ? moments : mom;
-        LPD(3, lds1, (const float*)nullptr, (const float*)nullptr, acc_ws, wacc);
+        // operands through the LDS ring (first1_bn_bwd_ring_kernel) whenever the image fits a 32-bit buffer descriptor and a wave's
+        // pixel run + 2 fits its 64 lanes (G >= 2); UNET_AMD_FIRST_BWD_RING=0: the register-prefetch kernel (A/B runs)
+        static const bool ring_off = [] { const char* e = getenv("UNET_AMD_FIRST_BWD_RING"); return e && atoi(e) == 0; }();
+        const unsigned long long xbytes = (unsigned long long)N * H * W * 4ull;
+        if (!ring_off && G >= 2 && xbytes < 0xFFFFFF00ull && (long long)N * ((H + FR_ROWS - 1) / FR_ROWS) * ((W + 256 / G - 1) / (256 / G)) < (1ll << 30)) {
+            const long long rt = (long long)N * ((H + FR_ROWS - 1) / FR_ROWS) * ((W + 256 / G - 1) / (256 / G));
+            const int rgrid = (int)(rt < 512 ? rt : 512);          // two workgroups per CU are resident (register budget): one wave of them
+            size_t rl = first_ring_lds_bytes(); if (rl < lds1) rl = lds1;
+#define LR(T, R) hipLaunchKernelGGL((first1_bn_bwd_ring_kernel<T, R>), dim3(rgrid), dim3(256), rl, s, (const T*)dy, ldd, doff, x, w, bias, scale, shift, mean, invstd, N, H, W, Cout, (unsigned)xbytes, acc_ws, wacc)
+            if (dtype == UNET_BF16) { if (relu) LR(__bf16, true); else LR(__bf16, false); }
+            else { if (relu) LR(float, true); else LR(float, false); }
+#undef LR
+        } else {
+            LPD(3, lds1, (const float*)nullptr, (const float*)nullptr, acc_ws, wacc);
+        }
         UNET_LAUNCH_CHECK();
         hipLaunchKernelGGL(first1_bwd_finalize_kernel, dim3((Cout + 255) / 256), dim3(256), 0, s, acc_ws, wacc, mom_use, w, bias, scale, mean, invstd,
                            frozen, Cout, dgamma, dbeta, dbias, dw);
