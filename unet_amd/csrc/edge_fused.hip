@@ -655,37 +655,66 @@ __global__ __launch_bounds__(256) void affine_act_out_kernel(const T* __restrict
     float bk[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) bk[k] = bias != nullptr ? bias[k] : 0.f;
-    // every lane of a wave runs the same trip count so the shuffles below see all lanes
-    const long long iters = (M + (long long)gridDim.x * ppb - 1) / ((long long)gridDim.x * ppb);
+    // AO_U CONSECUTIVE pixels per thread and trip: all requests of the trip go out before the first value is used, and lane
+    // sub == 0 writes its pixels' logits of a class as one 16-byte store (a wave's 8 pixel slots: 128 contiguous bytes per class).
+    // One pixel per trip meant one 16-byte request per thread in flight and two 32-byte stores per wave behind every load,
+    // which the next trip's load then waited for (vmcnt is in order): 4.0 TB/s.  Every lane of a wave runs the same trip
+    // count so the shuffles below see all lanes.
+    constexpr int AO_U = 4;
+    const long long span = (long long)ppb * AO_U;                  // pixels per workgroup and trip
+    const long long iters = (M + (long long)gridDim.x * span - 1) / ((long long)gridDim.x * span);
+    // a thread's 4 pixels never straddle two images when 4 divides HW; the 16-byte store also needs an aligned base
+    const bool vec_ok = (HW % AO_U) == 0 && ((size_t)logits & 15) == 0;
     for (long long it = 0; it < iters; ++it) {
-        const long long p = (it * gridDim.x + blockIdx.x) * ppb + pslot;
-        float f[EPV];
+        const long long pbase = (it * gridDim.x + blockIdx.x) * span + (long long)pslot * AO_U;
+        uint4 vz[AO_U];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) f[e] = 0.f;
-        if (p < M && sub < G) {
-            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + sub * EPV), f);
+        for (int u = 0; u < AO_U; ++u)
+            if (pbase + u < M && sub < G) vz[u] = *(const uint4*)(z + (pbase + u) * ldz + zoff + sub * EPV);
+        float d[K][AO_U];
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float v = fmaf(f[e], sc[e], sh[e]);
-                f[e] = RELU ? fmaxf(v, 0.f) : v;
+        for (int u = 0; u < AO_U; ++u) {
+            const long long p = pbase + u;
+            float f[EPV];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) f[e] = 0.f;
+            if (p < M && sub < G) {
+                Vec16<T>::unpack(vz[u], f);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float v = fmaf(f[e], sc[e], sh[e]);
+                    f[e] = RELU ? fmaxf(v, 0.f) : v;
+                }
+                const uint4 o = Vec16<T>::pack(f);
+                if (y != nullptr) *(uint4*)(y + p * ldy + yoff + sub * EPV) = o;
+                Vec16<T>::unpack(o, f);                   // the 1x1 conv sees what a stored activation would hold
             }
-            const uint4 o = Vec16<T>::pack(f);
-            if (y != nullptr) *(uint4*)(y + p * ldy + yoff + sub * EPV) = o;
-            Vec16<T>::unpack(o, f);                   // the 1x1 conv sees what a stored activation would hold
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) s = fmaf(f[e], wr[k][e], s);
+                for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o);
+                d[k][u] = s + bk[k];
+            }
         }
-        float d[K];
+        if (sub == 0 && pbase < M) {
+            if (vec_ok && pbase + AO_U <= M) {
+                const long long n = pbase / HW, hw = pbase - n * HW;
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float s = 0.f;
+                for (int k = 0; k < K; ++k)
+                    *(float4*)(logits + (n * K + k) * HW + hw) = make_float4(d[k][0], d[k][1], d[k][2], d[k][3]);
+            } else {
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) s = fmaf(f[e], wr[k][e], s);
-            for (int o = 1; o < LP; o <<= 1) s += __shfl_xor(s, o);
-            d[k] = s + bk[k];
-        }
-        if (p < M && sub == 0) {
-            const long long n = p / HW, hw = p - n * HW;
+                for (int u = 0; u < AO_U; ++u) {
+                    const long long p = pbase + u;
+                    if (p < M) {
+                        const long long n = p / HW, hw = p - n * HW;
 #pragma unroll
-            for (int k = 0; k < K; ++k) logits[(n * K + k) * HW + hw] = d[k];
+                        for (int k = 0; k < K; ++k) logits[(n * K + k) * HW + hw] = d[k][u];
+                    }
+                }
+            }
         }
     }
 }
@@ -725,42 +754,65 @@ __global__ __launch_bounds__(256) void bn_bwd_out_kernel(const float* __restrict
 #pragma unroll
             for (int k = 0; k < K; ++k) wr[k][e] = w[k * C + c];
         }
-        for (long long p = (long long)blockIdx.x * m.PL + m.pl; p < M; p += (long long)gridDim.x * m.PL) {
-            const long long n = p / HW, hw = p - n * HW;
-            float fz[EPV], g[K];
-            Vec16<T>::unpack(*(const uint4*)(z + p * ldz + zoff + m.cg * EPV), fz);
+        // OUT_U pixels per trip, every request of the trip issued before the first value is used (one pixel per trip left one
+        // 16-byte request per thread in flight: 3.2 TB/s in pass 1); the image index comes from a 32-bit division where the
+        // tensor allows it
+        constexpr int OUT_U = PASS == 1 ? 4 : 1;            // pass 2 streams at 5 TB/s as it is; 4 pixels there cost it half its occupancy
+        const long long stride = (long long)gridDim.x * m.PL;
+        const bool small = M < (1ll << 31);
+        for (long long p0 = (long long)blockIdx.x * m.PL + m.pl; p0 < M; p0 += stride * OUT_U) {
+            uint4 vz[OUT_U];
+            float gg[OUT_U][K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) g[k] = dl[(n * K + k) * HW + hw];
-            float o[EPV];
+            for (int u = 0; u < OUT_U; ++u) {
+                const long long p = p0 + u * stride;
+                if (p < M) {
+                    vz[u] = *(const uint4*)(z + p * ldz + zoff + m.cg * EPV);
+                    const long long n = small ? (long long)((unsigned)p / (unsigned)HW) : p / HW;
+                    const float* dp = dl + p + n * (K - 1) * HW;           // dl[(n*K + k)*HW + hw] with hw = p - n*HW
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                float dyv = 0.f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) dyv = fmaf(g[k], wr[k][e], dyv);
-                dyv = round_to<T>(dyv);
-                const float a = fmaf(fz[e], sc[e], sh[e]);
-                const float d = (!RELU || a > 0.f) ? dyv : 0.f;
-                const float xh = (fz[e] - mu[e]) * is[e];
-                if constexpr (PASS == 1) {
-                    part[e] += d;
-                    part[EPV + e] += d * xh;
-                    const float yv = round_to<T>(RELU ? fmaxf(a, 0.f) : a);
-#pragma unroll
-                    for (int k = 0; k < K; ++k) pw[k][e] = fmaf(g[k], yv, pw[k][e]);
-                } else {
-                    o[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+                    for (int k = 0; k < K; ++k) gg[u][k] = dp[k * HW];
                 }
             }
-            if constexpr (PASS == 1) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) pb[k] += g[k];
-            } else {
-                const uint4 ov = Vec16<T>::pack(o);
-                *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = ov;
-                float fr[EPV];
-                Vec16<T>::unpack(ov, fr);              // sum what the consumers of dz will actually read
+            for (int u = 0; u < OUT_U; ++u) {
+                const long long p = p0 + u * stride;
+                if (p >= M) break;
+                float fz[EPV], g[K];
+                Vec16<T>::unpack(vz[u], fz);
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+                for (int k = 0; k < K; ++k) g[k] = gg[u][k];
+                float o[EPV];
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    float dyv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < K; ++k) dyv = fmaf(g[k], wr[k][e], dyv);
+                    dyv = round_to<T>(dyv);
+                    const float a = fmaf(fz[e], sc[e], sh[e]);
+                    const float d = (!RELU || a > 0.f) ? dyv : 0.f;
+                    const float xh = (fz[e] - mu[e]) * is[e];
+                    if constexpr (PASS == 1) {
+                        part[e] += d;
+                        part[EPV + e] += d * xh;
+                        const float yv = round_to<T>(RELU ? fmaxf(a, 0.f) : a);
+#pragma unroll
+                        for (int k = 0; k < K; ++k) pw[k][e] = fmaf(g[k], yv, pw[k][e]);
+                    } else {
+                        o[e] = sc[e] * (d - k1[e] - xh * k2[e]);
+                    }
+                }
+                if constexpr (PASS == 1) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) pb[k] += g[k];
+                } else {
+                    const uint4 ov = Vec16<T>::pack(o);
+                    *(uint4*)(dz + p * ldo + ooff + m.cg * EPV) = ov;
+                    float fr[EPV];
+                    Vec16<T>::unpack(ov, fr);              // sum what the consumers of dz will actually read
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) part[e] += fr[e];
+                }
             }
         }
     }
@@ -956,7 +1008,7 @@ extern "C" int unet_affine_act_out(int dtype, int relu, const void* z, int ldz, 
     const int LP = lanes_per_pixel2(C / epv);
     // one request per thread per trip and a shuffle reduction behind it: this pass wants MORE resident workgroups than the
     // read+write streaming passes (8 per CU: 290 us, 4 per CU: 377 us at 32 x 512^2 x 64)
-    long long gl = (M + 256 / LP - 1) / (256 / LP);
+    long long gl = (M + 4 * (256 / LP) - 1) / (4 * (256 / LP));    // AO_U = 4 pixels per thread and trip
     const int grid = (int)(gl > MAX_GRID ? MAX_GRID : (gl < 1 ? 1 : gl));
     hipStream_t s = (hipStream_t)stream;
 #define LO(T, KK, R) hipLaunchKernelGGL((affine_act_out_kernel<T, KK, R>), dim3(grid), dim3(256), 0, s, (const T*)z, ldz, zoff, scale, shift, w, bias, logits, (T*)y, ldy, yoff, M, HW, C, LP)
