@@ -18,9 +18,9 @@ bk = torch.zeros(K, device=dev)
 dl = torch.randn(N, K, H, H, device=dev) * 1e-3
 ws = ops.Workspace(dev)
 for rep in range(2):
-    t = [timeit(lambda: ops.conv_first_stats(x, w1, b1, ops.BF16)),
+    t = [timeit(lambda: ops.first_stats_moments(x, w1, b1)),
          timeit(lambda: ops.first_bn_act(x, w1, b1, st, y)),
          timeit(lambda: ops.first_bn_relu_bwd(z, x, w1, b1, st, ws)),
          timeit(lambda: ops.affine_act_out(z, st, wk, bk)),
          timeit(lambda: ops.bn_relu_bwd_out(dl, wk, z, dz, st, ws))]
-    print("first: stats %6.1f  bn_act %6.1f  bwd %6.1f us | last: act_out %6.1f  bwd_out %6.1f us" % tuple(v * 1e3 for v in t), flush=True)
+    print("first: moments-stats %6.1f  bn_act %6.1f  bwd %6.1f us | last: act_out %6.1f  bwd_out %6.1f us" % tuple(v * 1e3 for v in t), flush=True)

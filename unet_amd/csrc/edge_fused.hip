@@ -913,7 +913,10 @@ extern "C" int unet_first_bn_act(int dtype, int relu, const float* x, const floa
 static int launch_first_moments(const float* x, int N, int H, int W, double* mom, hipStream_t s) {
     const long long groups = (long long)N * H * ((W + 3) / 4);
     long long mg = (groups + 255) / 256;
-    if (mg > 256) mg = 256;                                     // 55 fp64 atomics per workgroup: keep them few
+    // 55 fp64 atomics per workgroup: keep them few -- but one workgroup per CU (256) left the pass latency-bound (104 us for
+    // 33 MB; 512: 82 us, 1024: 110, 2048: 120 -- the atomics take over); UNET_AMD_MOMENTS_GRID overrides (experiments)
+    static const long long cap = [] { const char* e = getenv("UNET_AMD_MOMENTS_GRID"); const long v = e ? atol(e) : 0; return (long long)(v > 0 ? v : 512); }();
+    if (mg > cap) mg = cap;
     hipLaunchKernelGGL(first1_moments_kernel, dim3((unsigned)mg), dim3(256), 0, s, x, N, H, W, mom);
     UNET_LAUNCH_CHECK();
     return 0;
